@@ -1,0 +1,110 @@
+"""ctypes mirror of include/aivc_hip.h (struct layouts, constants, prototypes).
+
+The same prototypes are bound twice: on libaivc_hip.so (device pointers, product path) by
+aivc_amd/_lib.py, and -- with the ``_ref`` suffix, host pointers -- on the CPU oracle by
+oracle/oracle.py (tests only).
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+AIVC_OK = 0
+ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
+          -4: 'AIVC_ERR_WORKSPACE'}
+
+MODE_CONV, MODE_TCONV, MODE_GDN, MODE_IGDN = 0, 1, 2, 3
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+
+AC_MAX_VAL = 256
+LP = 514
+CDF_ROW = 520
+BALLE_PARAMS = 43
+MAX_MAPS = 256
+RC_MAX_STREAMS = 8
+
+FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
+
+_f = C.c_void_p  # every buffer pointer travels as an integer address
+
+
+class ConvParams(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+                ('n', C.c_int32), ('h_in', C.c_int32), ('w_in', C.c_int32), ('c_in', C.c_int32),
+                ('h_out', C.c_int32), ('w_out', C.c_int32), ('c_out', C.c_int32),
+                ('act1', C.c_int32), ('act2', C.c_int32), ('algo', C.c_int32),
+                ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f)]
+
+
+class MapList(C.Structure):
+    _fields_ = [('n_maps', C.c_int32), ('idx', C.c_uint8 * MAX_MAPS)]
+
+    @classmethod
+    def make(cls, idx):
+        m = cls()
+        m.n_maps = len(idx)
+        for i, v in enumerate(idx):
+            m.idx[i] = int(v)
+        return m
+
+
+class RcStream(C.Structure):
+    _fields_ = [('in_off', C.c_uint64), ('out_off', C.c_uint64), ('row_off', C.c_uint64),
+                ('n_sym', C.c_uint32), ('in_len', C.c_uint32), ('out_cap', C.c_uint32),
+                ('plane', C.c_uint32)]
+
+
+class RcBatch(C.Structure):
+    _fields_ = [('n_streams', C.c_int32), ('reserved', C.c_int32), ('s', RcStream * RC_MAX_STREAMS)]
+
+
+_i32, _sz, _fl = C.c_int32, C.c_size_t, C.c_float
+_P = C.POINTER
+
+# name -> argtypes (without the trailing stream argument, which every entry takes)
+PROTOTYPES = {
+    'aivc_conv2d': [_P(ConvParams)],
+    'aivc_gdn_reparam': [_f, _f, _i32, _fl, _fl, _fl, _f, _f],
+    'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
+    'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
+    'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
+    'aivc_frame_to_yuv420': [_f, _i32, _i32, _i32, _i32, _f, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f],
+    'aivc_warp_blend': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],
+    'aivc_warp': [_f, _f, _i32, _i32, _i32, _i32, _f],
+    'aivc_hyper_params': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f],
+    'aivc_channel_gain': [_f, _f, _sz, _i32, _f],
+    'aivc_quantize_center': [_f, _f, _f, _sz, _i32, _f, _f],
+    'aivc_dequantize': [_f, _f, _f, _sz, _i32, _f],
+    'aivc_balle_cdf_table': [_f, _i32, _f, _f],
+    'aivc_nonzero_maps': [_f, _sz, _i32, _f],
+    'aivc_laplace_cdf_rows': [_f, _sz, _i32, _P(MapList), _f],
+    'aivc_laplace_bounds': [_f, _f, _sz, _i32, _P(MapList), _f],
+    'aivc_table_bounds': [_f, _f, _sz, _i32, _f],
+    'aivc_range_encode': [_f, _P(RcBatch), _f, _f],
+    'aivc_range_decode': [_f, _f, _P(RcBatch), _f],
+    'aivc_scatter_symbols': [_f, _sz, _i32, _P(MapList), _f],
+}
+
+
+def declare(lib, suffix=''):
+    """Attach argtypes/restype for every entry of the header; raises AttributeError when the
+    library does not export one of them."""
+    fns = {}
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name + suffix)
+        fn.argtypes = list(args) + [C.c_void_p]
+        fn.restype = C.c_int
+        fns[name] = fn
+    ver = getattr(lib, 'aivc_abi_version' + suffix)
+    ver.argtypes = []
+    ver.restype = C.c_int
+    fns['aivc_abi_version'] = ver
+    return fns
+
+
+def conv_out_size(mode, h, w, k, stride, pad):
+    if mode == MODE_CONV:
+        return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    if mode == MODE_TCONV:
+        return 2 * h, 2 * w
+    return h, w

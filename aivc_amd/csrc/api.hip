@@ -1,0 +1,59 @@
+// api.hip -- library identity, error plumbing and the conv dispatcher.
+#include <string.h>
+
+#include "common.h"
+
+namespace aivc {
+static thread_local char g_err[256] = "";
+void set_last_error(const char *msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return AIVC_OK;
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  set_last_error(buf);
+  return AIVC_ERR_LAUNCH;
+}
+}  // namespace aivc
+
+AIVC_EXPORT int aivc_abi_version(void) { return 1; }
+AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
+
+static int validate_conv(const aivc_conv_params *p) {
+  if (!p || !p->x || !p->w || !p->y) return AIVC_ERR_ARG;
+  const int k = p->ksize, s = p->stride;
+  if (k != 1 && k != 3 && k != 5) return AIVC_ERR_UNSUPPORTED;
+  if (p->n <= 0 || p->h_in <= 0 || p->w_in <= 0 || p->c_in <= 0 || p->c_out <= 0) return AIVC_ERR_ARG;
+  if (p->c_in % 4) return AIVC_ERR_ARG;
+  switch (p->mode) {
+    case AIVC_MODE_CONV:
+      if (s != 1 && s != 2) return AIVC_ERR_UNSUPPORTED;
+      if (p->pad != 0 && p->pad != k / 2) return AIVC_ERR_UNSUPPORTED;
+      if (p->h_out != (p->h_in + 2 * p->pad - k) / s + 1 || p->w_out != (p->w_in + 2 * p->pad - k) / s + 1)
+        return AIVC_ERR_ARG;
+      break;
+    case AIVC_MODE_TCONV:
+      if (s != 2 || k == 1 || p->h_out != 2 * p->h_in || p->w_out != 2 * p->w_in) return AIVC_ERR_ARG;
+      break;
+    case AIVC_MODE_GDN:
+    case AIVC_MODE_IGDN:
+      if (k != 1 || p->h_out != p->h_in || p->w_out != p->w_in || p->c_out != p->c_in) return AIVC_ERR_ARG;
+      break;
+    default:
+      return AIVC_ERR_UNSUPPORTED;
+  }
+  return AIVC_OK;
+}
+
+AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
+  int rc = validate_conv(p);
+  if (rc != AIVC_OK) return rc;
+  hipStream_t s = aivc::to_stream(stream);
+  if (p->algo == AIVC_ALGO_DIRECT) return aivc::conv2d_direct(*p, s);
+  if (p->algo == AIVC_ALGO_MFMA) return aivc::conv2d_mfma(*p, s);
+  if (aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma(*p, s);
+  return aivc::conv2d_direct(*p, s);
+}

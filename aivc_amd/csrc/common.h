@@ -1,0 +1,54 @@
+// common.h -- shared host/device helpers of libaivc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aivc_detmath.h"
+#include "../../include/aivc_hip.h"
+
+#define AIVC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace aivc {
+
+void set_last_error(const char *msg);
+int check_launch(const char *what);  // hipGetLastError() -> AIVC_OK / AIVC_ERR_LAUNCH
+
+static inline hipStream_t to_stream(aivc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+__device__ __forceinline__ float act_apply(int act, float v) {
+  switch (act) {
+    case AIVC_ACT_LEAKY: return v > 0.0f ? v : v * 0.01f;
+    case AIVC_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case AIVC_ACT_SIGMOID: return aivc_sigmoidf_det(v);
+    default: return v;
+  }
+}
+
+// Epilogue shared by every conv implementation (order fixed by include/aivc_hip.h).
+struct Epilogue {
+  const float *bias, *mul, *res, *xin;  // xin: GDN input (same pixel/channel indexing as y)
+  float *y;
+  int act1, act2, mode;
+  __device__ __forceinline__ void store(size_t opix, int co, int c_out, float acc) const {
+    float v = acc;
+    if (bias) v = v + bias[co];
+    if (mode == AIVC_MODE_GDN || mode == AIVC_MODE_IGDN) {
+      const float xc = xin[opix * c_out + co];
+      const float nrm = __builtin_sqrtf(v);
+      v = (mode == AIVC_MODE_IGDN) ? xc * nrm : xc / nrm;
+    }
+    v = act_apply(act1, v);
+    const size_t o = opix * c_out + co;
+    if (mul) v = mul[o] * v;
+    if (res) v = v + res[o];
+    v = act_apply(act2, v);
+    y[o] = v;
+  }
+};
+
+int conv2d_direct(const aivc_conv_params &p, hipStream_t s);
+int conv2d_mfma(const aivc_conv_params &p, hipStream_t s);  // AIVC_ERR_UNSUPPORTED if shape not covered
+bool conv2d_mfma_supported(const aivc_conv_params &p);
+
+}  // namespace aivc

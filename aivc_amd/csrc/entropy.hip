@@ -1,0 +1,502 @@
+// entropy.hip -- hyperprior entropy model + torchac-compatible range coder for gfx950.
+//
+// CDF build (massively parallel, fp64 transcendentals from aivc_detmath.h):
+//   balle_cdf_table      one thread per (channel, k)          once per model load
+//   laplace_cdf_rows     one thread per 8 CDF points (16 B)   decoder: a 1040-byte uint16 row per
+//                        symbol position, so the serial decoder only does lookups
+//   laplace_bounds       one thread per symbol                encoder: the 2 CDF values it needs
+// Range coder (format-mandated: ONE serial stream per latent section):
+//   one 64-lane wavefront per stream, streams of a batch run concurrently on different CUs.
+//   All coder state is wave-uniform, so it lives in SGPRs / the scalar ALU; the vector lanes are
+//   used for what is parallel inside one symbol step:
+//     encode: lanes fetch 64 packed (c_lo,c_hi) pairs at once (coalesced), v_readlane feeds the
+//             scalar update; E1/E2/E3 renormalisation loops are collapsed into clz-based closed
+//             forms (s_flbit), bits are packed MSB-first through a 64-bit shifter.
+//     decode: each lane owns 8 consecutive CDF entries of the symbol's row (one 16-byte load,
+//             prefetched two groups ahead because the row address never depends on coder state);
+//             "largest m with cdf[m] <= count" is a ballot + popcount instead of torchac's
+//             10-step binary search.
+#include "common.h"
+
+namespace aivc {
+
+// ------------------------------------------------------------------ factorised prior (z) table
+__device__ float balle_cdf_point(const float *P, float t) {
+  const float *h0 = P, *h1 = P + 3, *h2 = P + 12, *h3 = P + 21;
+  const float *b0 = P + 24, *b1 = P + 27, *b2 = P + 30, *b3 = P + 33;
+  const float *a0 = P + 34, *a1 = P + 37, *a2 = P + 40;
+  float v[3], nv[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float x = t * aivc_softplusf_det(h0[r]);
+    x = x + b0[r];
+    v[r] = x + aivc_tanhf_det(a0[r]) * aivc_tanhf_det(x);
+  }
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const float *hh = l == 0 ? h1 : h2;
+    const float *bb = l == 0 ? b1 : b2;
+    const float *aa = l == 0 ? a1 : a2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float acc = v[0] * aivc_softplusf_det(hh[0 * 3 + r]);
+      acc = __builtin_fmaf(v[1], aivc_softplusf_det(hh[1 * 3 + r]), acc);
+      acc = __builtin_fmaf(v[2], aivc_softplusf_det(hh[2 * 3 + r]), acc);
+      const float x = acc + bb[r];
+      nv[r] = x + aivc_tanhf_det(aa[r]) * aivc_tanhf_det(x);
+    }
+    v[0] = nv[0];
+    v[1] = nv[1];
+    v[2] = nv[2];
+  }
+  float acc = v[0] * aivc_softplusf_det(h3[0]);
+  acc = __builtin_fmaf(v[1], aivc_softplusf_det(h3[1]), acc);
+  acc = __builtin_fmaf(v[2], aivc_softplusf_det(h3[2]), acc);
+  return aivc_sigmoidf_det(acc + b3[0]);
+}
+
+__global__ __launch_bounds__(256) void balle_cdf_table_kernel(const float *__restrict__ params, int c,
+                                                              uint16_t *__restrict__ table,
+                                                              float *__restrict__ cdf_f32) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= c * AIVC_CDF_ROW) return;
+  const int ch = gid / AIVC_CDF_ROW, k = gid % AIVC_CDF_ROW;
+  if (k >= AIVC_LP) {
+    table[gid] = 0;
+    return;
+  }
+  const float cdf = balle_cdf_point(params + (size_t)ch * AIVC_BALLE_PARAMS, (float)k - 256.5f);
+  if (cdf_f32) cdf_f32[(size_t)ch * AIVC_LP + k] = cdf;
+  table[gid] = aivc_cdf_quant(cdf, k);
+}
+
+// ------------------------------------------------------------------ non-zero feature maps
+__global__ __launch_bounds__(256) void nonzero_maps_kernel(const int16_t *__restrict__ q, size_t npix, int c,
+                                                           uint8_t *__restrict__ flags) {
+  // every writer stores the same value (1): deterministic without atomics
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * c; i += (size_t)gridDim.x * blockDim.x)
+    if (q[i] != 0) flags[i % c] = 1;
+}
+
+// ------------------------------------------------------------------ Laplace CDF rows / bounds
+__global__ __launch_bounds__(256) void laplace_cdf_rows_kernel(const float *__restrict__ sigma, size_t npix, int c,
+                                                               aivc_map_list maps, uint16_t *__restrict__ rows) {
+  constexpr int CHUNKS = AIVC_CDF_ROW / 8;  // 65 x 16 B per row
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)maps.n_maps * npix * CHUNKS;
+  if (gid >= total) return;
+  const int chunk = (int)(gid % CHUNKS);
+  const size_t pos = gid / CHUNKS;
+  const int m = (int)(pos / npix);
+  const size_t pix = pos % npix;
+  const float s = sigma[pix * c + maps.idx[m]];
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k0 = chunk * 8 + 2 * j, k1 = k0 + 1;
+    const uint32_t lo = k0 < AIVC_LP ? aivc_laplace_cdf_u16(k0, s) : 0;
+    const uint32_t hi = k1 < AIVC_LP ? aivc_laplace_cdf_u16(k1, s) : 0;
+    w[j] = lo | (hi << 16);
+  }
+  *reinterpret_cast<uint4 *>(rows + pos * AIVC_CDF_ROW + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void laplace_bounds_kernel(const float *__restrict__ sigma,
+                                                             const int16_t *__restrict__ q, size_t npix, int c,
+                                                             aivc_map_list maps, uint32_t *__restrict__ bounds) {
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (size_t)maps.n_maps * npix) return;
+  const int ch = maps.idx[pos / npix];
+  const size_t pix = pos % npix;
+  const float s = sigma[pix * c + ch];
+  const int sym = (int)q[pix * c + ch] + AIVC_AC_MAX_VAL;
+  const uint32_t lo = aivc_laplace_cdf_u16(sym, s), hi = aivc_laplace_cdf_u16(sym + 1, s);
+  bounds[pos] = lo | (hi << 16);
+}
+
+__global__ __launch_bounds__(256) void table_bounds_kernel(const uint16_t *__restrict__ table,
+                                                           const int16_t *__restrict__ q, size_t npix, int c,
+                                                           uint32_t *__restrict__ bounds) {
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (size_t)c * npix) return;
+  const int ch = (int)(pos / npix);
+  const size_t pix = pos % npix;
+  const int sym = (int)q[pix * c + ch] + AIVC_AC_MAX_VAL;
+  const uint16_t *row = table + (size_t)ch * AIVC_CDF_ROW;
+  bounds[pos] = (uint32_t)row[sym] | ((uint32_t)row[sym + 1] << 16);
+}
+
+struct InvMap {
+  int16_t slot[AIVC_MAX_MAPS];  // channel -> position in the coded list, or -1
+};
+__global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__restrict__ sym, size_t npix, int c,
+                                                              InvMap inv, int16_t *__restrict__ q) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * c) return;
+  const int ch = (int)(gid % c);
+  const size_t pix = gid / c;
+  const int m = inv.slot[ch];
+  q[gid] = m < 0 ? (int16_t)0 : (int16_t)((int)sym[(size_t)m * npix + pix] - AIVC_AC_MAX_VAL);
+}
+
+// ------------------------------------------------------------------ range encoder
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+struct BitSink {
+  uint32_t *out;       // 4-byte aligned
+  uint32_t cap_words;  // capacity in 32-bit words
+  uint32_t n_words;
+  uint64_t acc;
+  int nbits;  // < 32 between calls
+  bool overflow;
+  __device__ __forceinline__ void put(uint32_t bits, int nb, int lane) {  // nb in [1, 32]
+    acc = (acc << nb) | (uint64_t)bits;
+    nbits += nb;
+    if (nbits >= 32) {
+      const uint32_t word = (uint32_t)(acc >> (nbits - 32));
+      if (n_words < cap_words) {
+        if (lane == 0) out[n_words] = __builtin_bswap32(word);
+      } else {
+        overflow = true;
+      }
+      n_words++;
+      nbits -= 32;
+    }
+  }
+  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count, int lane) {
+    while (count > 0) {
+      const int r = count > 32 ? 32 : (int)count;
+      const uint32_t ones = r == 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+      put(bit ? ones : 0u, r, lane);
+      count -= r;
+    }
+  }
+};
+
+__global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__restrict__ bounds, aivc_rc_batch batch,
+                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
+  const aivc_rc_stream st = batch.s[blockIdx.x];
+  const int lane = threadIdx.x;
+  BitSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, false};
+  uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+  const uint32_t *src = bounds + st.in_off;
+  for (uint32_t base = 0; base < st.n_sym; base += 64) {
+    const uint32_t mine = (base + lane < st.n_sym) ? src[base + lane] : 0u;
+    const int cnt = (st.n_sym - base) < 64u ? (int)(st.n_sym - base) : 64;
+    for (int j = 0; j < cnt; ++j) {
+      const uint32_t b = rl(mine, j);
+      const uint32_t c_lo = b & 0xFFFFu, c_hi = b >> 16;
+      const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+      high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
+      low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
+      // E1 / E2: the n leading bits on which low and high agree are final
+      const int n = __builtin_clz(low ^ high);  // low < high always: 0 <= n <= 31
+      if (n > 0) {
+        const uint32_t b0 = low >> 31;
+        sink.put(b0, 1, lane);
+        sink.put_run(b0 ^ 1u, pending, lane);
+        pending = 0;
+        if (n > 1) sink.put((low << 1) >> (33 - n), n - 1, lane);
+        low <<= n;
+        high = (high << n) | ((1u << n) - 1u);
+      }
+      // E3: now low = 0..., high = 1...; every further position with (low,high) = (1,0) straddles
+      const uint32_t y = (low & ~high) << 1;
+      const int m = __builtin_clz(~y);  // leading ones of y (0..31)
+      if (m > 0) {
+        pending += (uint32_t)m;
+        low = (low << m) & 0x7FFFFFFFu;
+        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      }
+    }
+  }
+  pending += 1;
+  const uint32_t fb = low < 0x40000000u ? 0u : 1u;
+  sink.put(fb, 1, lane);
+  sink.put_run(fb ^ 1u, pending, lane);
+  // flush the last partial word byte by byte (zero padded to a byte boundary)
+  uint32_t total = sink.n_words * 4u;
+  if (sink.nbits > 0) {
+    const int nbytes = (sink.nbits + 7) / 8;
+    const uint32_t word = (uint32_t)(sink.acc << (32 - sink.nbits));  // MSB aligned, zero padded
+    for (int i = 0; i < nbytes; ++i) {
+      if (total + i < st.out_cap) {
+        if (lane == 0) out[st.out_off + total + i] = (uint8_t)(word >> (24 - 8 * i));
+      } else {
+        sink.overflow = true;
+      }
+    }
+    total += nbytes;
+  }
+  if (lane == 0) out_len[blockIdx.x] = sink.overflow ? 0xFFFFFFFFu : total;
+}
+
+// ------------------------------------------------------------------ range decoder
+struct BitSrc {
+  const uint32_t *in;  // 4-byte aligned, zero padded
+  uint32_t n_words;    // words that may be read (beyond: zeros)
+  uint32_t tail_bytes; // payload bytes in the last word (0 = all four)
+  uint32_t wi;         // next word index
+  uint32_t chunk;      // per-lane: word (wi & ~63) + lane
+  uint64_t win;        // upcoming bits, MSB aligned
+  int avail;
+  int lane;
+  __device__ __forceinline__ void load_chunk() {
+    const uint32_t idx = (wi & ~63u) + (uint32_t)lane;
+    uint32_t w = idx < n_words ? in[idx] : 0u;
+    // bytes past the payload end read as zero bits (torchac: "missing bits are 0")
+    if (idx + 1 == n_words && tail_bytes) w &= (1u << (8 * tail_bytes)) - 1u;
+    chunk = w;
+  }
+  __device__ __forceinline__ uint32_t next_word() {
+    const uint32_t w = __builtin_bswap32(rl(chunk, (int)(wi & 63u)));
+    wi++;
+    if ((wi & 63u) == 0) load_chunk();
+    return w;
+  }
+  __device__ __forceinline__ void init() {
+    wi = 0;
+    load_chunk();
+    win = (uint64_t)next_word() << 32;
+    win |= (uint64_t)next_word();
+    avail = 64;
+  }
+  __device__ __forceinline__ uint32_t take(int n) {  // n in [0, 32]
+    if (n == 0) return 0u;
+    const uint32_t v = (uint32_t)(win >> (64 - n));
+    win <<= n;
+    avail -= n;
+    if (avail <= 32) {
+      win |= (uint64_t)next_word() << (32 - avail);
+      avail += 32;
+    }
+    return v;
+  }
+};
+
+constexpr int DEC_G = 8;  // symbols per prefetch group
+
+struct RowRegs {
+  uint4 e;      // 8 consecutive uint16 CDF entries: 8*lane .. 8*lane+7
+  uint32_t nx;  // entry 8*lane+8
+};
+
+__device__ __forceinline__ uint32_t sel16(const uint4 &e, int idx) {  // idx in [0, 7]
+  const uint32_t d = idx < 2 ? e.x : (idx < 4 ? e.y : (idx < 6 ? e.z : e.w));
+  return (idx & 1) ? (d >> 16) : (d & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
+                                                          const uint16_t *__restrict__ rows, aivc_rc_batch batch,
+                                                          uint16_t *__restrict__ sym) {
+  const aivc_rc_stream st = batch.s[blockIdx.x];
+  const int lane = threadIdx.x;
+  if (st.n_sym == 0) return;
+  BitSrc src;
+  src.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
+  src.n_words = (st.in_len + 3u) / 4u;
+  src.tail_bytes = st.in_len & 3u;
+  src.lane = lane;
+  src.init();
+  uint32_t low = 0, high = 0xFFFFFFFFu;
+  uint32_t value = src.take(32);
+
+  // row bookkeeping for the prefetcher (independent of coder state)
+  uint64_t pf_row = st.row_off;
+  uint32_t pf_in_plane = 0;
+  auto fetch = [&](RowRegs &r, bool valid) {
+    if (valid) {
+      const uint16_t *row = rows + pf_row * AIVC_CDF_ROW;
+      r.e = *reinterpret_cast<const uint4 *>(row + lane * 8);
+      r.nx = row[lane * 8 + 8];
+      if (st.plane == 0) {
+        pf_row++;
+      } else if (++pf_in_plane == st.plane) {
+        pf_in_plane = 0;
+        pf_row++;
+      }
+    } else {
+      r.e = make_uint4(0, 0, 0, 0);
+      r.nx = 0;
+    }
+  };
+
+  RowRegs cur[DEC_G], nxt[DEC_G];
+#pragma unroll
+  for (int g = 0; g < DEC_G; ++g) fetch(cur[g], (uint32_t)g < st.n_sym);
+
+  uint32_t mysym = 0;
+  for (uint32_t base = 0; base < st.n_sym; base += DEC_G) {
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g) fetch(nxt[g], base + DEC_G + g < st.n_sym);
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g) {
+      const uint32_t i = base + g;
+      if (i < st.n_sym) {
+        const uint4 e = cur[g].e;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const uint64_t num = ((((uint64_t)value - (uint64_t)low) + 1) << 16) - 1;
+        // exact: the quotient is < 2^16 and the denominator < 2^33, so the correctly rounded
+        // fp64 quotient can never cross an integer boundary
+        const uint32_t count = (uint32_t)((double)num / (double)span);
+        int cnt = 0;
+        cnt += (e.x & 0xFFFFu) <= count;
+        cnt += (e.x >> 16) <= count;
+        cnt += (e.y & 0xFFFFu) <= count;
+        cnt += (e.y >> 16) <= count;
+        cnt += (e.z & 0xFFFFu) <= count;
+        cnt += (e.z >> 16) <= count;
+        cnt += (e.w & 0xFFFFu) <= count;
+        cnt += (e.w >> 16) <= count;
+        const unsigned long long mask = __ballot((e.x & 0xFFFFu) <= count);
+        int L = __builtin_popcountll(mask) - 1;
+        L = L < 0 ? 0 : L;
+        const int idx = cnt > 0 ? cnt - 1 : 0;
+        const uint32_t lo_l = sel16(e, idx);
+        const uint32_t hi_l = idx == 7 ? cur[g].nx : sel16(e, idx + 1);
+        const uint32_t packed = lo_l | (hi_l << 16) | 0u;
+        const uint32_t pk = rl(packed, L);
+        const int idxL = (int)rl((uint32_t)idx, L);
+        uint32_t m = (uint32_t)(8 * L + idxL);
+        uint32_t pk2 = pk;
+        {  // symbol 512 (never produced by our encoder) keeps torchac's semantics on foreign streams
+          const uint32_t e512 = rl(cur[g].nx, 63);
+          if (m == 511u && e512 <= count) {
+            m = 512u;
+            pk2 = e512;  // c_hi = 0x10000 handled below
+          }
+        }
+        if (lane == (int)(i & 63u)) mysym = m;
+        if ((i & 63u) == 63u || i == st.n_sym - 1) {
+          const uint32_t first = i & ~63u;
+          if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
+        }
+        if (i != st.n_sym - 1) {
+          const uint32_t c_lo = pk2 & 0xFFFFu, c_hi = m == 512u ? 0x10000u : (pk2 >> 16);
+          high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
+          low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
+          const int n = __builtin_clz(low ^ high);
+          if (n > 0) {
+            low <<= n;
+            high = (high << n) | ((1u << n) - 1u);
+            value = (value << n) | src.take(n);
+          }
+          const uint32_t y = (low & ~high) << 1;
+          const int m3 = __builtin_clz(~y);
+          if (m3 > 0) {
+            low = (low << m3) & 0x7FFFFFFFu;
+            high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
+            value = ((value << m3) ^ 0x80000000u) | src.take(m3);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g) cur[g] = nxt[g];
+  }
+}
+
+}  // namespace aivc
+
+using namespace aivc;
+
+AIVC_EXPORT int aivc_balle_cdf_table(const float *params, int32_t c, uint16_t *table, float *cdf_f32,
+                                     aivc_stream_t stream) {
+  if (!params || !table || c <= 0) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(balle_cdf_table_kernel, dim3(cdiv((size_t)c * AIVC_CDF_ROW, 256)), dim3(256), 0,
+                     to_stream(stream), params, c, table, cdf_f32);
+  return check_launch("balle_cdf_table");
+}
+
+AIVC_EXPORT int aivc_nonzero_maps(const int16_t *q, size_t npix, int32_t c, uint8_t *flags, aivc_stream_t stream) {
+  if (!q || !flags || c <= 0 || c > AIVC_MAX_MAPS) return AIVC_ERR_ARG;
+  if (hipMemsetAsync(flags, 0, c, to_stream(stream)) != hipSuccess) return check_launch("nonzero_maps memset");
+  if (npix == 0) return AIVC_OK;
+  unsigned grid = cdiv(npix * c, 256 * 8);
+  grid = grid > 2048 ? 2048 : (grid == 0 ? 1 : grid);
+  hipLaunchKernelGGL(nonzero_maps_kernel, dim3(grid), dim3(256), 0, to_stream(stream), q, npix, c, flags);
+  return check_launch("nonzero_maps");
+}
+
+static int check_maps(const aivc_map_list *maps, int c) {
+  if (!maps || maps->n_maps < 0 || maps->n_maps > c || c > AIVC_MAX_MAPS) return AIVC_ERR_ARG;
+  for (int i = 0; i < maps->n_maps; ++i)
+    if (maps->idx[i] >= c) return AIVC_ERR_ARG;
+  return AIVC_OK;
+}
+
+AIVC_EXPORT int aivc_laplace_cdf_rows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps,
+                                      uint16_t *rows, aivc_stream_t stream) {
+  if (!sigma || !rows || c <= 0) return AIVC_ERR_ARG;
+  if (int rc = check_maps(maps, c)) return rc;
+  const size_t total = (size_t)maps->n_maps * npix * (AIVC_CDF_ROW / 8);
+  if (total == 0) return AIVC_OK;
+  hipLaunchKernelGGL(laplace_cdf_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), sigma, npix,
+                     c, *maps, rows);
+  return check_launch("laplace_cdf_rows");
+}
+
+AIVC_EXPORT int aivc_laplace_bounds(const float *sigma, const int16_t *q, size_t npix, int32_t c,
+                                    const aivc_map_list *maps, uint32_t *bounds, aivc_stream_t stream) {
+  if (!sigma || !q || !bounds || c <= 0) return AIVC_ERR_ARG;
+  if (int rc = check_maps(maps, c)) return rc;
+  const size_t total = (size_t)maps->n_maps * npix;
+  if (total == 0) return AIVC_OK;
+  hipLaunchKernelGGL(laplace_bounds_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), sigma, q, npix,
+                     c, *maps, bounds);
+  return check_launch("laplace_bounds");
+}
+
+AIVC_EXPORT int aivc_table_bounds(const uint16_t *table, const int16_t *q, size_t npix, int32_t c, uint32_t *bounds,
+                                  aivc_stream_t stream) {
+  if (!table || !q || !bounds || c <= 0) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(table_bounds_kernel, dim3(cdiv((size_t)c * npix, 256)), dim3(256), 0, to_stream(stream), table,
+                     q, npix, c, bounds);
+  return check_launch("table_bounds");
+}
+
+AIVC_EXPORT int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c, const aivc_map_list *maps,
+                                     int16_t *q, aivc_stream_t stream) {
+  if (!q || c <= 0) return AIVC_ERR_ARG;
+  if (int rc = check_maps(maps, c)) return rc;
+  if (maps->n_maps > 0 && !sym) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  InvMap inv;
+  for (int i = 0; i < AIVC_MAX_MAPS; ++i) inv.slot[i] = -1;
+  for (int i = 0; i < maps->n_maps; ++i) inv.slot[maps->idx[i]] = (int16_t)i;
+  hipLaunchKernelGGL(scatter_symbols_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), sym, npix,
+                     c, inv, q);
+  return check_launch("scatter_symbols");
+}
+
+static int check_batch(const aivc_rc_batch *b) {
+  if (!b || b->n_streams < 0 || b->n_streams > AIVC_RC_MAX_STREAMS) return AIVC_ERR_ARG;
+  return AIVC_OK;
+}
+
+AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *batch, uint8_t *out,
+                                  uint32_t *out_len, aivc_stream_t stream) {
+  if (!out || !out_len) return AIVC_ERR_ARG;
+  if (int rc = check_batch(batch)) return rc;
+  if (batch->n_streams == 0) return AIVC_OK;
+  for (int i = 0; i < batch->n_streams; ++i) {
+    if (batch->s[i].out_off % 4) return AIVC_ERR_ARG;
+    if (batch->s[i].n_sym && !bounds) return AIVC_ERR_ARG;
+  }
+  hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch,
+                     out, out_len);
+  return check_launch("range_encode");
+}
+
+AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_batch *batch,
+                                  uint16_t *sym, aivc_stream_t stream) {
+  if (!bytes || !rows || !sym) return AIVC_ERR_ARG;
+  if (int rc = check_batch(batch)) return rc;
+  if (batch->n_streams == 0) return AIVC_OK;
+  for (int i = 0; i < batch->n_streams; ++i)
+    if (batch->s[i].in_off % 4) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(range_decode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, rows,
+                     *batch, sym);
+  return check_launch("range_decode");
+}

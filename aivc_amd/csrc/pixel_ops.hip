@@ -1,0 +1,376 @@
+// pixel_ops.hip -- HBM-bound frame / latent kernels: 4:2:0 <-> 4:4:4, motion-compensation warp +
+// blend, reconstruction + 8-bit cast, hyper-prior parameter split, gains, (de)quantisation.
+// One thread per pixel (channels are innermost, so a pixel's channels sit in one or two
+// cache lines); grids are sized >> 256 CUs for every frame size the codec handles.
+#include "common.h"
+
+namespace aivc {
+
+// ---------------------------------------------------------------- 4:2:0 -> 4:4:4 (InputLayer)
+template <typename T>
+__global__ __launch_bounds__(256) void yuv420_to_444_kernel(const T *__restrict__ y, const T *__restrict__ u,
+                                                            const T *__restrict__ v, int n, int h, int w,
+                                                            float *__restrict__ out, int c_store, int c_off,
+                                                            int zero_pad) {
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n * h * w;
+  if (pix >= total) return;
+  const int c = (int)(pix % w), r = (int)((pix / w) % h), b = (int)(pix / ((size_t)w * h));
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const size_t ci = ((size_t)b * hc + r / 2) * wc + c / 2;
+  float fy, fu, fv;
+  if (sizeof(T) == 1) {
+    fy = (float)y[pix] / 255.0f;
+    fu = (float)u[ci] / 255.0f;
+    fv = (float)v[ci] / 255.0f;
+  } else {
+    fy = (float)y[pix];
+    fu = (float)u[ci];
+    fv = (float)v[ci];
+  }
+  float *o = out + pix * c_store + c_off;
+  if (zero_pad && ((c_store & 3) == 0) && ((c_off & 3) == 0)) {
+    *reinterpret_cast<float4 *>(o) = make_float4(fy, fu, fv, 0.0f);
+  } else {
+    o[0] = fy;
+    o[1] = fu;
+    o[2] = fv;
+    if (zero_pad) o[3] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------- reconstruction tail
+__device__ __forceinline__ float cast8(float x, uint8_t *byte) {
+  float c = x < 0.0f ? 0.0f : x;
+  c = c > 1.0f ? 1.0f : c;
+  const float r = __builtin_rintf(255.0f * c);
+  *byte = (uint8_t)r;
+  return r / 255.0f;
+}
+
+struct RecArgs {
+  const float *x, *skip;
+  int n, hx, wx, cx, cs, h, w;
+  float *y, *u, *v;
+  uint8_t *y8, *u8, *v8;
+};
+
+__device__ __forceinline__ float xhat(const RecArgs &a, int b, int r, int c, int ch) {
+  float val = a.x[(((size_t)b * a.hx + r) * a.wx + c) * a.cx + ch];
+  if (a.skip) val = val + a.skip[(((size_t)b * a.h + r) * a.w + c) * a.cs + ch];
+  return val;
+}
+
+// one thread per chroma sample: writes U, V and the (up to) 2x2 luma samples it covers
+__global__ __launch_bounds__(256) void frame_to_yuv420_kernel(RecArgs a) {
+  const int hc = (a.h + 1) / 2, wc = (a.w + 1) / 2;
+  const int hf = a.h / 2, wf = a.w / 2;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.n * hc * wc;
+  if (gid >= total) return;
+  const int c = (int)(gid % wc), r = (int)((gid / wc) % hc), b = (int)(gid / ((size_t)wc * hc));
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const int yy = 2 * r + dy, xx = 2 * c + dx;
+      if (yy < a.h && xx < a.w) {
+        uint8_t byte;
+        const float lv = cast8(xhat(a, b, yy, xx, 0), &byte);
+        const size_t o = ((size_t)b * a.h + yy) * a.w + xx;
+        if (a.y) a.y[o] = lv;
+        if (a.y8) a.y8[o] = byte;
+      }
+    }
+  const int rr = min(r, max(hf - 1, 0)), cc = min(c, max(wf - 1, 0));
+  for (int ch = 1; ch <= 2; ++ch) {
+    float val = 0.0f;
+    if (hf > 0 && wf > 0) {
+      const float p00 = xhat(a, b, 2 * rr, 2 * cc, ch), p01 = xhat(a, b, 2 * rr, 2 * cc + 1, ch);
+      const float p10 = xhat(a, b, 2 * rr + 1, 2 * cc, ch), p11 = xhat(a, b, 2 * rr + 1, 2 * cc + 1, ch);
+      const float top = 0.5f * p00 + 0.5f * p01;
+      const float bot = 0.5f * p10 + 0.5f * p11;
+      val = 0.5f * top + 0.5f * bot;
+    }
+    uint8_t byte;
+    const float lv = cast8(val, &byte);
+    float *dst = ch == 1 ? a.u : a.v;
+    uint8_t *dst8 = ch == 1 ? a.u8 : a.v8;
+    if (dst) dst[gid] = lv;
+    if (dst8) dst8[gid] = byte;
+  }
+}
+
+// ---------------------------------------------------------------- warp (grid_sample bilinear/border)
+__device__ __forceinline__ float warp_coord(float pos, int size) {
+  const int d = size - 1 > 1 ? size - 1 : 1;
+  const float g = 2.0f * pos / (float)d - 1.0f;
+  float ix = ((g + 1.0f) / 2.0f) * (float)(size - 1);
+  ix = ix < 0.0f ? 0.0f : ix;
+  ix = ix > (float)(size - 1) ? (float)(size - 1) : ix;
+  return ix;
+}
+
+struct WarpTap {
+  int o00, o01, o10, o11;  // pixel offsets (or -1 when out of bounds)
+  float nw, ne, sw, se;
+};
+__device__ __forceinline__ WarpTap warp_taps(int h, int w, float fx, float fy, int row, int col) {
+  const float ix = warp_coord((float)col + fx, w);
+  const float iy = warp_coord((float)row + fy, h);
+  const float x0 = __builtin_floorf(ix), y0 = __builtin_floorf(iy);
+  const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+  WarpTap t;
+  t.nw = (x1 - ix) * (y1 - iy);
+  t.ne = (ix - x0) * (y1 - iy);
+  t.sw = (x1 - ix) * (iy - y0);
+  t.se = (ix - x0) * (iy - y0);
+  const int xi0 = (int)x0, yi0 = (int)y0, xi1 = xi0 + 1, yi1 = yi0 + 1;
+  const bool x0ok = xi0 >= 0 && xi0 < w, x1ok = xi1 >= 0 && xi1 < w;
+  const bool y0ok = yi0 >= 0 && yi0 < h, y1ok = yi1 >= 0 && yi1 < h;
+  t.o00 = (y0ok && x0ok) ? yi0 * w + xi0 : -1;
+  t.o01 = (y0ok && x1ok) ? yi0 * w + xi1 : -1;
+  t.o10 = (y1ok && x0ok) ? yi1 * w + xi0 : -1;
+  t.o11 = (y1ok && x1ok) ? yi1 * w + xi1 : -1;
+  return t;
+}
+__device__ __forceinline__ float warp_apply(const float *img, int c, int ch, const WarpTap &t) {
+  float res = 0.0f;
+  if (t.o00 >= 0) res = res + img[(size_t)t.o00 * c + ch] * t.nw;
+  if (t.o01 >= 0) res = res + img[(size_t)t.o01 * c + ch] * t.ne;
+  if (t.o10 >= 0) res = res + img[(size_t)t.o10 * c + ch] * t.sw;
+  if (t.o11 >= 0) res = res + img[(size_t)t.o11 * c + ch] * t.se;
+  return res;
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ x, const float *__restrict__ flow,
+                                                   int n, int h, int w, int c, float *__restrict__ out) {
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (size_t)n * h * w) return;
+  const int q = (int)(pix % w), r = (int)((pix / w) % h), b = (int)(pix / ((size_t)w * h));
+  const float *img = x + (size_t)b * h * w * c;
+  const WarpTap t = warp_taps(h, w, flow[pix * 2], flow[pix * 2 + 1], r, q);
+  for (int ch = 0; ch < c; ++ch) out[pix * c + ch] = warp_apply(img, c, ch, t);
+}
+
+struct BlendArgs {
+  const float *mof, *prev, *next;
+  int hm, wm, cm, cr, n, h, w, frame_type, co;
+  float *pred, *skip, *x_warp, *alpha_out, *beta_out;
+};
+__global__ __launch_bounds__(256) void warp_blend_kernel(BlendArgs a) {
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (size_t)a.n * a.h * a.w) return;
+  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.h), b = (int)(pix / ((size_t)a.w * a.h));
+  const float *m = a.mof + (((size_t)b * a.hm + r) * a.wm + q) * a.cm;
+  float alpha = m[0] + 0.5f;
+  alpha = alpha < 0.0f ? 0.0f : (alpha > 1.0f ? 1.0f : alpha);
+  float beta = m[1] + 0.5f;
+  beta = beta < 0.0f ? 0.0f : (beta > 1.0f ? 1.0f : beta);
+  float vpx = m[2], vpy = m[3], vnx = m[4], vny = m[5];
+  if (a.frame_type == 1) {
+    beta = 1.0f;
+    vnx = 0.0f;
+    vny = 0.0f;
+  }
+  if (a.alpha_out) a.alpha_out[pix] = alpha;
+  if (a.beta_out) a.beta_out[pix] = beta;
+  const float *pimg = a.prev + (size_t)b * a.h * a.w * a.cr;
+  const float *nimg = a.next + (size_t)b * a.h * a.w * a.cr;
+  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, r, q);
+  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, r, q);
+  for (int ch = 0; ch < a.co; ++ch) {
+    float xw = 0.0f, pr = 0.0f, sk = 0.0f;
+    if (ch < 3) {
+      const float wp = warp_apply(pimg, a.cr, ch, tp);
+      const float wn = warp_apply(nimg, a.cr, ch, tn);
+      const float t1 = beta * wp;
+      const float t2 = (1.0f - beta) * wn;
+      xw = t1 + t2;
+      pr = xw * alpha;
+      sk = (1.0f - alpha) * xw;
+    }
+    if (a.x_warp) a.x_warp[pix * a.co + ch] = xw;
+    if (a.pred) a.pred[pix * a.co + ch] = pr;
+    if (a.skip) a.skip[pix * a.co + ch] = sk;
+  }
+}
+
+// ---------------------------------------------------------------- latent ops
+__global__ __launch_bounds__(256) void hyper_params_kernel(const float *__restrict__ hs, int n, int hh, int wh,
+                                                           int c, int h, int w, float *__restrict__ mu,
+                                                           float *__restrict__ sigma) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n * h * w * c;
+  if (gid >= total) return;
+  const int ch = (int)(gid % c);
+  const size_t pix = gid / c;
+  const int q = (int)(pix % w), r = (int)((pix / w) % h), b = (int)(pix / ((size_t)w * h));
+  const float *src = hs + (((size_t)b * hh + r) * wh + q) * 2 * c;
+  mu[gid] = src[ch];
+  float lv = src[c + ch];
+  lv = lv < -18.4207f ? -18.4207f : lv;
+  lv = lv > 10.0f ? 10.0f : lv;
+  sigma[gid] = aivc_expf_det(0.5f * lv);
+}
+
+__global__ __launch_bounds__(256) void channel_gain_kernel(const float *__restrict__ in, const float *__restrict__ gain,
+                                                           size_t total, int c, float *__restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  out[gid] = gain ? in[gid] * __builtin_fabsf(gain[gid % c]) : in[gid];
+}
+
+__global__ __launch_bounds__(256) void quantize_center_kernel(const float *__restrict__ y, const float *__restrict__ mu,
+                                                              const float *__restrict__ gain, size_t total, int c,
+                                                              int16_t *__restrict__ q, float *__restrict__ y_hat) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const float m = mu ? mu[gid] : 0.0f;
+  float r = __builtin_rintf(mu ? y[gid] - m : y[gid]);
+  r = r < -256.0f ? -256.0f : (r > 255.0f ? 255.0f : r);
+  if (q) q[gid] = (int16_t)r;
+  if (y_hat) {
+    float v = mu ? r + m : r;
+    if (gain) v = v * __builtin_fabsf(gain[gid % c]);
+    y_hat[gid] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dequantize_kernel(const int16_t *__restrict__ q, const float *__restrict__ mu,
+                                                         const float *__restrict__ gain, size_t total, int c,
+                                                         float *__restrict__ y_hat) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  float v = mu ? (float)q[gid] + mu[gid] : (float)q[gid];
+  if (gain) v = v * __builtin_fabsf(gain[gid % c]);
+  y_hat[gid] = v;
+}
+
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float *__restrict__ in, size_t npix, int c_in,
+                                                           float *__restrict__ out, int c_out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * c_out) return;
+  const int c = (int)(gid % c_out);
+  const size_t p = gid / c_out;
+  out[gid] = c < c_in ? in[p * c_in + c] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void gdn_reparam_kernel(const float *__restrict__ beta, const float *__restrict__ gamma,
+                                                          int c, float beta_bound, float gamma_bound, float pedestal,
+                                                          float *__restrict__ beta_eff, float *__restrict__ gamma_eff) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < c) {
+    const float b = beta[gid] > beta_bound ? beta[gid] : beta_bound;
+    beta_eff[gid] = b * b - pedestal;
+  }
+  if (gid < c * c) {
+    const float g = gamma[gid] > gamma_bound ? gamma[gid] : gamma_bound;
+    gamma_eff[gid] = g * g - pedestal;
+  }
+}
+
+}  // namespace aivc
+
+using namespace aivc;
+
+AIVC_EXPORT int aivc_gdn_reparam(const float *beta, const float *gamma, int32_t c, float beta_bound,
+                                 float gamma_bound, float pedestal, float *beta_eff, float *gamma_eff,
+                                 aivc_stream_t stream) {
+  if (!beta || !gamma || !beta_eff || !gamma_eff || c <= 0) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(gdn_reparam_kernel, dim3(cdiv((size_t)c * c, 256)), dim3(256), 0, to_stream(stream), beta,
+                     gamma, c, beta_bound, gamma_bound, pedestal, beta_eff, gamma_eff);
+  return check_launch("gdn_reparam");
+}
+
+AIVC_EXPORT int aivc_pad_channels(const float *in, size_t npix, int32_t c_in, float *out, int32_t c_out,
+                                  aivc_stream_t stream) {
+  if (!in || !out || c_out < c_in || c_in <= 0) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(cdiv(npix * c_out, 256)), dim3(256), 0, to_stream(stream), in, npix,
+                     c_in, out, c_out);
+  return check_launch("pad_channels");
+}
+
+AIVC_EXPORT int aivc_yuv420_to_444(const float *y, const float *u, const float *v, int32_t n, int32_t h, int32_t w,
+                                   float *out, int32_t c_store, int32_t c_off, int32_t zero_pad,
+                                   aivc_stream_t stream) {
+  if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
+  if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(yuv420_to_444_kernel<float>, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream),
+                     y, u, v, n, h, w, out, c_store, c_off, zero_pad);
+  return check_launch("yuv420_to_444");
+}
+
+AIVC_EXPORT int aivc_yuv420u8_to_444(const uint8_t *y, const uint8_t *u, const uint8_t *v, int32_t n, int32_t h,
+                                     int32_t w, float *out, int32_t c_store, int32_t c_off, int32_t zero_pad,
+                                     aivc_stream_t stream) {
+  if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
+  if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(yuv420_to_444_kernel<uint8_t>, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0,
+                     to_stream(stream), y, u, v, n, h, w, out, c_store, c_off, zero_pad);
+  return check_launch("yuv420u8_to_444");
+}
+
+AIVC_EXPORT int aivc_frame_to_yuv420(const float *x, int32_t n, int32_t hx, int32_t wx, int32_t cx, const float *skip,
+                                     int32_t cs, int32_t h, int32_t w, float *y, float *u, float *v, uint8_t *y8,
+                                     uint8_t *u8, uint8_t *v8, aivc_stream_t stream) {
+  if (!x || n <= 0 || h <= 0 || w <= 0 || hx < h || wx < w || cx < 3) return AIVC_ERR_ARG;
+  if (skip && cs < 3) return AIVC_ERR_ARG;
+  RecArgs a{x, skip, n, hx, wx, cx, cs, h, w, y, u, v, y8, u8, v8};
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2);
+  hipLaunchKernelGGL(frame_to_yuv420_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), a);
+  return check_launch("frame_to_yuv420");
+}
+
+AIVC_EXPORT int aivc_warp(const float *x, const float *flow, int32_t n, int32_t h, int32_t w, int32_t c, float *out,
+                          aivc_stream_t stream) {
+  if (!x || !flow || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(warp_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), x, flow, n, h,
+                     w, c, out);
+  return check_launch("warp");
+}
+
+AIVC_EXPORT int aivc_warp_blend(const float *mof, int32_t hm, int32_t wm, int32_t cm, const float *prev,
+                                const float *next, int32_t cr, int32_t n, int32_t h, int32_t w, int32_t frame_type,
+                                float *pred, float *skip, float *x_warp, int32_t co, float *alpha_out,
+                                float *beta_out, aivc_stream_t stream) {
+  if (!mof || !prev || !next || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
+  if (hm < h || wm < w || cm < 6 || cr < 3 || co < 3) return AIVC_ERR_ARG;
+  BlendArgs a{mof, prev, next, hm, wm, cm, cr, n, h, w, frame_type, co, pred, skip, x_warp, alpha_out, beta_out};
+  hipLaunchKernelGGL(warp_blend_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), a);
+  return check_launch("warp_blend");
+}
+
+AIVC_EXPORT int aivc_hyper_params(const float *hs, int32_t n, int32_t hh, int32_t wh, int32_t c, int32_t h, int32_t w,
+                                  float *mu, float *sigma, aivc_stream_t stream) {
+  if (!hs || !mu || !sigma || n <= 0 || c <= 0 || h <= 0 || w <= 0 || hh < h || wh < w) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(hyper_params_kernel, dim3(cdiv((size_t)n * h * w * c, 256)), dim3(256), 0, to_stream(stream), hs,
+                     n, hh, wh, c, h, w, mu, sigma);
+  return check_launch("hyper_params");
+}
+
+AIVC_EXPORT int aivc_channel_gain(const float *in, const float *gain, size_t npix, int32_t c, float *out,
+                                  aivc_stream_t stream) {
+  if (!in || !out || c <= 0) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(channel_gain_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), in, gain,
+                     npix * c, c, out);
+  return check_launch("channel_gain");
+}
+
+AIVC_EXPORT int aivc_quantize_center(const float *y, const float *mu, const float *gain_dec, size_t npix, int32_t c,
+                                     int16_t *q, float *y_hat, aivc_stream_t stream) {
+  if (!y || c <= 0 || (!q && !y_hat)) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(quantize_center_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), y, mu,
+                     gain_dec, npix * c, c, q, y_hat);
+  return check_launch("quantize_center");
+}
+
+AIVC_EXPORT int aivc_dequantize(const int16_t *q, const float *mu, const float *gain_dec, size_t npix, int32_t c,
+                                float *y_hat, aivc_stream_t stream) {
+  if (!q || !y_hat || c <= 0) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(dequantize_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), q, mu, gain_dec,
+                     npix * c, c, y_hat);
+  return check_launch("dequantize");
+}

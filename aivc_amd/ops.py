@@ -1,0 +1,325 @@
+"""Tensor-level wrappers over the C ABI (include/aivc_hip.h).
+
+PyTorch is used for device memory and streams only: every function takes CUDA tensors, hands raw
+device pointers to libaivc_hip.so on torch's current stream and returns freshly allocated CUDA
+tensors.  Feature maps are NHWC fp32 ([n, h, w, c], contiguous).  CPU tensors are rejected: the
+product has no CPU execution path (the CPU restatement lives in oracle/ and is test-only).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from ._lib import AivcNativeError, call
+
+FRAME_I, FRAME_P, FRAME_B = abi.FRAME_I, abi.FRAME_P, abi.FRAME_B
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=None, name='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AivcNativeError('aivc_amd.ops: %s is on %s; the HIP path needs CUDA tensors '
+                              '(no CPU fallback)' % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise AivcNativeError('aivc_amd.ops: %s has dtype %s, expected %s' % (name, t.dtype, dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# NCHW (logical, torch module API) <-> NHWC (physical, kernels) -------------------------------
+def to_nhwc(x):
+    """[n,c,h,w] tensor (any strides) -> contiguous [n,h,w,c] (free when x is channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw_view(x):
+    """[n,h,w,c] contiguous -> logical [n,c,h,w] view (channels_last strides, no copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def pad_channels(x, c_out):
+    x = _dev(x, torch.float32, 'x')
+    c_in = x.shape[-1]
+    if c_in == c_out:
+        return x
+    out = torch.empty(x.shape[:-1] + (c_out,), dtype=torch.float32, device=x.device)
+    call('aivc_pad_channels', _p(x), x.numel() // c_in, c_in, _p(out), c_out, _stream())
+    return out
+
+
+def pack_weight(w, c_store=None, transposed=False):
+    """torch Conv2d weight [O,I,kh,kw] (ConvTranspose2d: [I,O,kh,kw]) -> OHWI fp32 contiguous with
+    the input-channel axis zero padded to c_store (pure data movement, done once per layer)."""
+    w = w.detach()
+    if transposed:
+        w = w.permute(1, 0, 2, 3)
+    w = w.permute(0, 2, 3, 1)
+    ci = w.shape[3]
+    c_store = ci if c_store is None else c_store
+    if c_store != ci:
+        wp = torch.zeros(w.shape[:3] + (c_store,), dtype=torch.float32, device=w.device)
+        wp[..., :ci] = w
+        return wp
+    return w.contiguous().float()
+
+
+def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
+           res=None, algo=abi.ALGO_AUTO):
+    """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h)."""
+    x = _dev(x, torch.float32, 'x')
+    n, h, w_, c = x.shape
+    if c % 4:
+        x = pad_channels(x, (c + 3) // 4 * 4)
+        c = x.shape[-1]
+    w_ohwi = _dev(w_ohwi, torch.float32, 'weight')
+    co, k, _, cw = w_ohwi.shape
+    if cw != c:
+        raise AivcNativeError('conv2d: weight packed for %d stored channels, input has %d' % (cw, c))
+    ho, wo = abi.conv_out_size(mode, h, w_, k, stride, pad)
+    y = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
+    bias = _dev(bias, torch.float32, 'bias')
+    mul = _dev(mul, torch.float32, 'mul')
+    res = _dev(res, torch.float32, 'res')
+    for t, nm in ((mul, 'mul'), (res, 'res')):
+        if t is not None and tuple(t.shape) != tuple(y.shape):
+            raise AivcNativeError('conv2d: %s shape %s != output shape %s' % (nm, tuple(t.shape), tuple(y.shape)))
+    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo,
+                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y))
+    call('aivc_conv2d', C.byref(p), _stream())
+    return y
+
+
+def gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
+    beta = _dev(beta.detach(), torch.float32, 'beta')
+    gamma = _dev(gamma.detach(), torch.float32, 'gamma')
+    c = beta.shape[0]
+    be = torch.empty_like(beta)
+    ge = torch.empty_like(gamma)
+    call('aivc_gdn_reparam', _p(beta), _p(gamma), c, float(beta_bound), float(gamma_bound),
+         float(pedestal), _p(be), _p(ge), _stream())
+    return be, ge
+
+
+def gdn(x, beta_eff, gamma_eff, inverse=False, res=None, algo=abi.ALGO_AUTO):
+    c = x.shape[-1]
+    return conv2d(x, gamma_eff.reshape(c, 1, 1, c), beta_eff,
+                  mode=abi.MODE_IGDN if inverse else abi.MODE_GDN, res=res, algo=algo)
+
+
+def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
+    """planes [n,h,w] / [n,ceil(h/2),ceil(w/2)] (fp32 levels or uint8) -> NHWC [n,h,w,c_store]"""
+    u8 = y.dtype == torch.uint8
+    dt = torch.uint8 if u8 else torch.float32
+    y, u, v = _dev(y, dt, 'y'), _dev(u, dt, 'u'), _dev(v, dt, 'v')
+    n, h, w = y.shape
+    if out is None:
+        out = torch.zeros((n, h, w, c_store), dtype=torch.float32, device=y.device)
+    zero_pad = 1 if out.shape[-1] >= c_off + 4 else 0
+    call('aivc_yuv420u8_to_444' if u8 else 'aivc_yuv420_to_444', _p(y), _p(u), _p(v), n, h, w,
+         _p(out), out.shape[-1], c_off, zero_pad, _stream())
+    return out
+
+
+def frame_to_yuv420(x, h, w, skip=None, want_float=True, want_u8=True):
+    x = _dev(x, torch.float32, 'x')
+    skip = _dev(skip, torch.float32, 'skip')
+    n, hx, wx, cx = x.shape
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    dev = x.device
+    f = [None] * 3
+    b = [None] * 3
+    if want_float:
+        f = [torch.empty((n, h, w), dtype=torch.float32, device=dev),
+             torch.empty((n, hc, wc), dtype=torch.float32, device=dev),
+             torch.empty((n, hc, wc), dtype=torch.float32, device=dev)]
+    if want_u8:
+        b = [torch.empty((n, h, w), dtype=torch.uint8, device=dev),
+             torch.empty((n, hc, wc), dtype=torch.uint8, device=dev),
+             torch.empty((n, hc, wc), dtype=torch.uint8, device=dev)]
+    call('aivc_frame_to_yuv420', _p(x), n, hx, wx, cx, _p(skip), 0 if skip is None else skip.shape[-1],
+         h, w, _p(f[0]), _p(f[1]), _p(f[2]), _p(b[0]), _p(b[1]), _p(b[2]), _stream())
+    return tuple(f), tuple(b)
+
+
+def warp(x, flow):
+    x, flow = _dev(x, torch.float32, 'x'), _dev(flow, torch.float32, 'flow')
+    n, h, w, c = x.shape
+    out = torch.empty_like(x)
+    call('aivc_warp', _p(x), _p(flow), n, h, w, c, _p(out), _stream())
+    return out
+
+
+def warp_blend(mof, prev, nxt, h, w, frame_type, co=4, want_aux=False):
+    mof, prev, nxt = (_dev(t, torch.float32, nm) for t, nm in ((mof, 'mof'), (prev, 'prev'), (nxt, 'next')))
+    n, hm, wm, cm = mof.shape
+    dev = mof.device
+    pred = torch.empty((n, h, w, co), dtype=torch.float32, device=dev)
+    skip = torch.empty_like(pred)
+    xw = alpha = beta = None
+    if want_aux:
+        xw = torch.empty_like(pred)
+        alpha = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+        beta = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+    call('aivc_warp_blend', _p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
+         int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha), _p(beta), _stream())
+    return {'pred': pred, 'skip': skip, 'x_warp': xw, 'alpha': alpha, 'beta': beta}
+
+
+def hyper_params(hs, c, h, w):
+    hs = _dev(hs, torch.float32, 'hs')
+    n, hh, wh, c2 = hs.shape
+    if c2 != 2 * c:
+        raise AivcNativeError('hyper_params: expected %d channels, got %d' % (2 * c, c2))
+    mu = torch.empty((n, h, w, c), dtype=torch.float32, device=hs.device)
+    sigma = torch.empty_like(mu)
+    call('aivc_hyper_params', _p(hs), n, hh, wh, c, h, w, _p(mu), _p(sigma), _stream())
+    return mu, sigma
+
+
+def channel_gain(x, gain):
+    x = _dev(x, torch.float32, 'x')
+    gain = None if gain is None else _dev(gain.detach().reshape(-1), torch.float32, 'gain')
+    out = torch.empty_like(x)
+    call('aivc_channel_gain', _p(x), _p(gain), x.numel() // x.shape[-1], x.shape[-1], _p(out), _stream())
+    return out
+
+
+def quantize_center(y, mu=None, gain_dec=None, want_yhat=True):
+    y = _dev(y, torch.float32, 'y')
+    mu = _dev(mu, torch.float32, 'mu')
+    gain_dec = None if gain_dec is None else _dev(gain_dec.detach().reshape(-1), torch.float32, 'gain')
+    q = torch.empty(y.shape, dtype=torch.int16, device=y.device)
+    y_hat = torch.empty_like(y) if want_yhat else None
+    call('aivc_quantize_center', _p(y), _p(mu), _p(gain_dec), y.numel() // y.shape[-1], y.shape[-1],
+         _p(q), _p(y_hat), _stream())
+    return q, y_hat
+
+
+def dequantize(q, mu=None, gain_dec=None):
+    q = _dev(q, torch.int16, 'q')
+    mu = _dev(mu, torch.float32, 'mu')
+    gain_dec = None if gain_dec is None else _dev(gain_dec.detach().reshape(-1), torch.float32, 'gain')
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    call('aivc_dequantize', _p(q), _p(mu), _p(gain_dec), q.numel() // q.shape[-1], q.shape[-1], _p(out),
+         _stream())
+    return out
+
+
+# entropy model ---------------------------------------------------------------------------------
+def balle_cdf_table(params, want_float=False):
+    params = _dev(params, torch.float32, 'params')
+    c = params.shape[0]
+    table = torch.empty((c, abi.CDF_ROW), dtype=torch.int16, device=params.device)  # uint16 payload
+    cdf = torch.empty((c, abi.LP), dtype=torch.float32, device=params.device) if want_float else None
+    call('aivc_balle_cdf_table', _p(params), c, _p(table), _p(cdf), _stream())
+    return (table, cdf) if want_float else table
+
+
+def nonzero_flags(q):
+    """device uint8 [c] flags (no host sync)"""
+    q = _dev(q, torch.int16, 'q')
+    c = q.shape[-1]
+    flags = torch.empty(c, dtype=torch.uint8, device=q.device)
+    call('aivc_nonzero_maps', _p(q), q.numel() // c, c, _p(flags), _stream())
+    return flags
+
+
+def laplace_cdf_rows(sigma, maps, out=None):
+    sigma = _dev(sigma, torch.float32, 'sigma')
+    c = sigma.shape[-1]
+    npix = sigma.numel() // c
+    ml = abi.MapList.make(maps)
+    if out is None:
+        out = torch.empty((len(maps) * npix, abi.CDF_ROW), dtype=torch.int16, device=sigma.device)
+    call('aivc_laplace_cdf_rows', _p(sigma), npix, c, C.byref(ml), _p(out), _stream())
+    return out
+
+
+def laplace_bounds(sigma, q, maps):
+    sigma, q = _dev(sigma, torch.float32, 'sigma'), _dev(q, torch.int16, 'q')
+    c = sigma.shape[-1]
+    npix = sigma.numel() // c
+    ml = abi.MapList.make(maps)
+    bounds = torch.empty(len(maps) * npix, dtype=torch.int32, device=sigma.device)
+    call('aivc_laplace_bounds', _p(sigma), _p(q), npix, c, C.byref(ml), _p(bounds), _stream())
+    return bounds
+
+
+def table_bounds(table, q):
+    q = _dev(q, torch.int16, 'q')
+    c = q.shape[-1]
+    npix = q.numel() // c
+    bounds = torch.empty(c * npix, dtype=torch.int32, device=q.device)
+    call('aivc_table_bounds', _p(table), _p(q), npix, c, _p(bounds), _stream())
+    return bounds
+
+
+def range_encode(bounds_list):
+    """bounds_list: up to 8 int32 CUDA tensors (one stream each).  Returns (out uint8 tensor,
+    lens int32 tensor [n], offsets list) -- all on device, no sync."""
+    n = len(bounds_list)
+    if n == 0 or n > abi.RC_MAX_STREAMS:
+        raise AivcNativeError('range_encode: 1..%d streams per call' % abi.RC_MAX_STREAMS)
+    dev = bounds_list[0].device
+    allb = bounds_list[0] if n == 1 else torch.cat(bounds_list)
+    batch = abi.RcBatch()
+    batch.n_streams = n
+    in_off, out_off, offs = 0, 0, []
+    for i, b in enumerate(bounds_list):
+        cap = 16 + 3 * b.numel()
+        cap = (cap + 3) // 4 * 4
+        s = batch.s[i]
+        s.in_off, s.out_off, s.n_sym, s.out_cap = in_off, out_off, b.numel(), cap
+        offs.append((out_off, cap))
+        in_off += b.numel()
+        out_off += cap
+    out = torch.empty(out_off, dtype=torch.uint8, device=dev)
+    lens = torch.empty(n, dtype=torch.int32, device=dev)
+    call('aivc_range_encode', _p(allb), C.byref(batch), _p(out), _p(lens), _stream())
+    return out, lens, offs
+
+
+def range_decode(payloads, rows_list, n_syms, planes):
+    """payloads: list of bytes objects; rows_list: CUDA int16 tensors [rows][CDF_ROW]; returns a
+    list of CUDA int16 tensors holding the decoded symbols (uint16 payload, values 0..512)."""
+    n = len(payloads)
+    if n == 0 or n > abi.RC_MAX_STREAMS:
+        raise AivcNativeError('range_decode: 1..%d streams per call' % abi.RC_MAX_STREAMS)
+    dev = rows_list[0].device
+    blob = bytearray()
+    batch = abi.RcBatch()
+    batch.n_streams = n
+    # all rows tensors must live in one allocation for a batched call; keep it simple: one call
+    # per distinct rows tensor
+    outs = []
+    for i in range(n):
+        pl = payloads[i]
+        padded = len(pl) + (-len(pl)) % 4 + 8
+        host = torch.zeros(padded, dtype=torch.uint8)
+        host[:len(pl)] = torch.frombuffer(bytearray(pl), dtype=torch.uint8) if len(pl) else host[:0]
+        dbytes = host.to(dev, non_blocking=True)
+        sym = torch.empty(n_syms[i], dtype=torch.int16, device=dev)
+        b1 = abi.RcBatch()
+        b1.n_streams = 1
+        s = b1.s[0]
+        s.in_off, s.out_off, s.row_off, s.n_sym, s.in_len, s.plane = 0, 0, 0, n_syms[i], len(pl), planes[i]
+        call('aivc_range_decode', _p(dbytes), _p(rows_list[i]), C.byref(b1), _p(sym), _stream())
+        outs.append(sym)
+    return outs
+
+
+def scatter_symbols(sym, npix, c, maps):
+    ml = abi.MapList.make(maps)
+    dev = sym.device if sym is not None else torch.device('cuda')
+    q = torch.empty((npix, c), dtype=torch.int16, device=dev)
+    call('aivc_scatter_symbols', _p(sym), npix, c, C.byref(ml), _p(q), _stream())
+    return q

@@ -1,0 +1,211 @@
+/*
+ * aivc_detmath.h -- deterministic transcendentals shared by the HIP kernels and the CPU oracle.
+ *
+ * The codec's encoder and decoder must derive bit-identical sigma / CDF values, and the HIP path
+ * must be checkable bit for bit against the CPU oracle, so nothing here may depend on a libm or
+ * on device intrinsics whose rounding differs between hosts and GPUs.  Everything is built from
+ * IEEE-754 binary64 add / mul / fma / div and integer bit operations, which are correctly rounded
+ * on x86-64 and on gfx950 alike (compile with -ffp-contract=off; every fused operation below is an
+ * explicit fma()).  Results are accurate to a few binary64 ulps, i.e. they round to the correctly
+ * rounded binary32 value except in ~1e-9 of the cases, which is the accuracy class of the fp32
+ * torch/SLEEF kernels the reference uses (src/real_life/bitstream.py:127-154,
+ * src/layers/misc/misc_layers.py:203-219, src/layers/entropy_coding/pdf_estimator.py:204-245).
+ *
+ * This header is NOT part of the oracle: it is a numerical primitive of the product that the
+ * oracle re-uses so that "same inputs -> same bits" is a meaningful test.  Its accuracy is pinned
+ * independently in tests/test_detmath.py against libm and against torch-generated golden vectors.
+ */
+#ifndef AIVC_DETMATH_H
+#define AIVC_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AIVC_HD __host__ __device__ static inline
+#define AIVC_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define AIVC_RINT(a) __builtin_rint((a))
+#define AIVC_FABS(a) __builtin_fabs((a))
+#else
+#include <math.h>
+#define AIVC_HD static inline
+#define AIVC_FMA(a, b, c) fma((a), (b), (c))
+#define AIVC_RINT(a) rint((a))
+#define AIVC_FABS(a) fabs((a))
+#endif
+
+AIVC_HD double aivc_bits_to_f64(uint64_t u) {
+  union { uint64_t u; double d; } c;
+  c.u = u;
+  return c.d;
+}
+AIVC_HD uint64_t aivc_f64_to_bits(double d) {
+  union { uint64_t u; double d; } c;
+  c.d = d;
+  return c.u;
+}
+/* 2^k for -1022 <= k <= 1023 */
+AIVC_HD double aivc_pow2i(int k) { return aivc_bits_to_f64((uint64_t)(k + 1023) << 52); }
+
+/* exp(x), |rel err| < ~2 ulp(binary64) */
+AIVC_HD double aivc_det_exp(double x) {
+  if (x != x) return x;
+  if (x > 709.0) return aivc_bits_to_f64(0x7FF0000000000000ull);
+  if (x < -745.0) return 0.0;
+  const double INV_LN2 = 1.4426950408889634074;
+  const double LN2_HI = 6.93147180369123816490e-01; /* 0x3FE62E42FEE00000 */
+  const double LN2_LO = 1.90821492927058770002e-10; /* 0x3DEA39EF35793C76 */
+  const double kd = AIVC_RINT(x * INV_LN2);
+  double r = AIVC_FMA(-kd, LN2_HI, x);
+  r = AIVC_FMA(-kd, LN2_LO, r);
+  /* Taylor, degree 13: |r| <= 0.3466 -> truncation < 2^-57 */
+  double p = 1.0 / 6227020800.0;
+  p = AIVC_FMA(p, r, 1.0 / 479001600.0);
+  p = AIVC_FMA(p, r, 1.0 / 39916800.0);
+  p = AIVC_FMA(p, r, 1.0 / 3628800.0);
+  p = AIVC_FMA(p, r, 1.0 / 362880.0);
+  p = AIVC_FMA(p, r, 1.0 / 40320.0);
+  p = AIVC_FMA(p, r, 1.0 / 5040.0);
+  p = AIVC_FMA(p, r, 1.0 / 720.0);
+  p = AIVC_FMA(p, r, 1.0 / 120.0);
+  p = AIVC_FMA(p, r, 1.0 / 24.0);
+  p = AIVC_FMA(p, r, 1.0 / 6.0);
+  p = AIVC_FMA(p, r, 0.5);
+  p = AIVC_FMA(p, r, 1.0);
+  p = AIVC_FMA(p, r, 1.0);
+  const int k = (int)kd;
+  const int k1 = k / 2;
+  const int k2 = k - k1;
+  return (p * aivc_pow2i(k1)) * aivc_pow2i(k2);
+}
+
+/* expm1(x) */
+AIVC_HD double aivc_det_expm1(double x) {
+  if (x != x) return x;
+  if (AIVC_FABS(x) < 0.34) {
+    /* x * (1 + x/2 + x^2/6 + ...), degree 16 in total */
+    double p = 1.0 / 20922789888000.0; /* 1/16! */
+    p = AIVC_FMA(p, x, 1.0 / 1307674368000.0);
+    p = AIVC_FMA(p, x, 1.0 / 87178291200.0);
+    p = AIVC_FMA(p, x, 1.0 / 6227020800.0);
+    p = AIVC_FMA(p, x, 1.0 / 479001600.0);
+    p = AIVC_FMA(p, x, 1.0 / 39916800.0);
+    p = AIVC_FMA(p, x, 1.0 / 3628800.0);
+    p = AIVC_FMA(p, x, 1.0 / 362880.0);
+    p = AIVC_FMA(p, x, 1.0 / 40320.0);
+    p = AIVC_FMA(p, x, 1.0 / 5040.0);
+    p = AIVC_FMA(p, x, 1.0 / 720.0);
+    p = AIVC_FMA(p, x, 1.0 / 120.0);
+    p = AIVC_FMA(p, x, 1.0 / 24.0);
+    p = AIVC_FMA(p, x, 1.0 / 6.0);
+    p = AIVC_FMA(p, x, 0.5);
+    p = AIVC_FMA(p, x, 1.0);
+    return p * x;
+  }
+  if (x < -60.0) return -1.0;
+  return aivc_det_exp(x) - 1.0;
+}
+
+/* log(x) for finite x > 0 (normal or subnormal) */
+AIVC_HD double aivc_det_log(double x) {
+  uint64_t b = aivc_f64_to_bits(x);
+  int e = 0;
+  if ((b >> 52) == 0) { /* subnormal: scale up */
+    x = x * 18014398509481984.0; /* 2^54 */
+    b = aivc_f64_to_bits(x);
+    e = -54;
+  }
+  e += (int)((b >> 52) & 0x7FF) - 1023;
+  uint64_t mb = (b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m = aivc_bits_to_f64(mb); /* [1, 2) */
+  if (m > 1.4142135623730951) {
+    m = m * 0.5;
+    e += 1;
+  }
+  const double f = (m - 1.0) / (m + 1.0); /* |f| <= 0.1716 */
+  const double s = f * f;
+  /* 2*atanh(f) = 2f (1 + s/3 + s^2/5 + ... + s^12/25) */
+  double p = 1.0 / 25.0;
+  p = AIVC_FMA(p, s, 1.0 / 23.0);
+  p = AIVC_FMA(p, s, 1.0 / 21.0);
+  p = AIVC_FMA(p, s, 1.0 / 19.0);
+  p = AIVC_FMA(p, s, 1.0 / 17.0);
+  p = AIVC_FMA(p, s, 1.0 / 15.0);
+  p = AIVC_FMA(p, s, 1.0 / 13.0);
+  p = AIVC_FMA(p, s, 1.0 / 11.0);
+  p = AIVC_FMA(p, s, 1.0 / 9.0);
+  p = AIVC_FMA(p, s, 1.0 / 7.0);
+  p = AIVC_FMA(p, s, 1.0 / 5.0);
+  p = AIVC_FMA(p, s, 1.0 / 3.0);
+  p = AIVC_FMA(p, s, 1.0);
+  const double lm = 2.0 * f * p;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  const double ed = (double)e;
+  return AIVC_FMA(ed, LN2_HI, AIVC_FMA(ed, LN2_LO, lm));
+}
+
+/* log1p(y) for y >= 0 */
+AIVC_HD double aivc_det_log1p(double y) {
+  if (y < 1e-5) { /* y - y^2/2 + y^3/3 : rel err < 1e-16 */
+    double p = AIVC_FMA(y, 1.0 / 3.0, -0.5);
+    p = AIVC_FMA(p, y, 1.0);
+    return p * y;
+  }
+  const double u = 1.0 + y;
+  const double c = y - (u - 1.0); /* rounding error of 1+y */
+  return aivc_det_log(u) + c / u;
+}
+
+/* ---- fp32 wrappers mirroring the reference's fp32 torch ops ---- */
+AIVC_HD float aivc_expf_det(float x) { return (float)aivc_det_exp((double)x); }
+AIVC_HD float aivc_expm1f_det(float x) {
+  /* exp(-17.5) < 2^-25, so fp32(expm1(x)) is exactly -1 below that (saves the fp64 work in the
+   * saturated tails of the Laplace CDF) */
+  if (x < -17.5f) return -1.0f;
+  return (float)aivc_det_expm1((double)x);
+}
+/* torch.sigmoid(float): 1 / (1 + exp(-x)) evaluated in fp32 */
+AIVC_HD float aivc_sigmoidf_det(float x) {
+  const float e = aivc_expf_det(-x);
+  const float d = 1.0f + e;
+  return 1.0f / d;
+}
+/* torch.tanh(float) */
+AIVC_HD float aivc_tanhf_det(float x) {
+  const double ax = AIVC_FABS((double)x);
+  if (ax > 20.0) return x > 0 ? 1.0f : -1.0f;
+  const double em = aivc_det_expm1(2.0 * ax);
+  const double t = em / (em + 2.0);
+  return (float)(x < 0 ? -t : t);
+}
+/* torch.nn.functional.softplus(float) with beta = 1, threshold = 20 */
+AIVC_HD float aivc_softplusf_det(float x) {
+  if (x > 20.0f) return x;
+  return (float)aivc_det_log1p(aivc_det_exp((double)x));
+}
+
+/* Laplace(0, sigma/sqrt(2)).cdf(t) in the reference's fp32 op order
+ * (torch.distributions.Laplace.cdf: 0.5 - 0.5 * sign(t) * expm1(-|t| / b)). */
+AIVC_HD float aivc_laplace_cdf(float t, float sigma) {
+  const float b = sigma / 1.41421354f; /* sqrt(fp32 2.0) */
+  const float at = t < 0.0f ? -t : t;
+  const float a = at / b;
+  const float e = aivc_expm1f_det(-a);
+  const float hs = t < 0.0f ? -0.5f : (t > 0.0f ? 0.5f : 0.0f);
+  return 0.5f - hs * e;
+}
+/* torchac float -> uint16 CDF quantisation for point k of an Lp = 514 row:
+ * int16 cast of round(cdf * (2^16 - (Lp - 1))) then + k, wrapping. */
+AIVC_HD uint16_t aivc_cdf_quant(float cdf, int k) {
+#if defined(__HIPCC__)
+  const float r = __builtin_rintf(cdf * 65023.0f);
+#else
+  const float r = rintf(cdf * 65023.0f);
+#endif
+  return (uint16_t)(((int32_t)r + k) & 0xFFFF);
+}
+AIVC_HD uint16_t aivc_laplace_cdf_u16(int k, float sigma) {
+  return aivc_cdf_quant(aivc_laplace_cdf((float)k - 256.5f, sigma), k);
+}
+
+#endif /* AIVC_DETMATH_H */

@@ -1,0 +1,262 @@
+/*
+ * aivc_hip.h -- C ABI of libaivc_hip.so: the MI355X (gfx950) native hot path of the
+ * AIVC learned video codec (frame transforms, motion compensation, entropy coding).
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes, no framework types.
+ *   - every entry point returns AIVC_OK (0) or a negative error code and never throws.
+ *   - all pointers are DEVICE pointers owned by the caller unless the name says "host".
+ *   - work is enqueued asynchronously on the caller's hipStream_t (passed as void*).
+ *   - the library keeps no global state and allocates nothing: scratch comes from the caller.
+ *   - results are deterministic: no atomics, fixed accumulation order (see "arithmetic
+ *     contract" below), so encoder and decoder agree bit for bit on every GPU.
+ *
+ * Feature maps are NHWC fp32 ("channels innermost").  The stored channel count of a conv
+ * input must be a multiple of 4 (callers zero-pad 3/6/9-channel images to 4/8/12).
+ *
+ * Each function names the reference code it replaces (paths relative to the upstream
+ * repository root, see SURVEY.md for the line-by-line mapping).  The CPU oracle
+ * (oracle/aivc_oracle.c) exports the same functions with a `_ref` suffix on HOST pointers;
+ * it is test infrastructure only.
+ *
+ * Arithmetic contract (what "bit exact" means for the fp32 ops):
+ *   conv-like ops accumulate   acc = fmaf(a, w, acc)   starting from +0.0f, iterating kernel
+ *   taps in (ky, kx) ascending order and, inside a tap, stored input channels ascending;
+ *   then v = acc + bias, then the epilogue in the order documented at aivc_conv2d.
+ *   v_mfma_f32_32x32x2_f32 implements exactly this k-ordered fmaf chain, so the MFMA
+ *   kernels, the scalar HIP kernels and the CPU oracle agree bitwise.
+ *   Transcendentals (exp for sigma / sigmoid, expm1 for the Laplace CDF, the factorised
+ *   prior's softplus/tanh/sigmoid) are evaluated by a fixed fp64 polynomial scheme
+ *   ("det_exp" family) and rounded once to fp32, identically on host and device.
+ */
+#ifndef AIVC_HIP_H
+#define AIVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *aivc_stream_t; /* hipStream_t */
+
+enum {
+  AIVC_OK = 0,
+  AIVC_ERR_ARG = -1,         /* null pointer / inconsistent sizes */
+  AIVC_ERR_UNSUPPORTED = -2, /* shape or option outside what the kernels implement */
+  AIVC_ERR_LAUNCH = -3,      /* hipLaunch / runtime error */
+  AIVC_ERR_WORKSPACE = -4    /* caller-provided buffer too small */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Library identity
+ * ---------------------------------------------------------------------------------------- */
+/* ABI version, bumped whenever a struct or signature changes. */
+int aivc_abi_version(void);
+/* Last HIP runtime error string seen by this thread's most recent failing call (host). */
+const char *aivc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family: CustomConvLayer / UpscalingLayer / GDN and the residual compositions
+ * built from them (ChengResBlock, ResBlock, AttentionResBlock, SimplifiedAttention).
+ * Replaces: src/layers/misc/custom_conv_layers.py:21-253, src/layers/misc/misc_layers.py:113-154,
+ *           src/layers/misc/attention.py:22-97 (ATen conv2d / conv_transpose2d / pad kernels).
+ * ---------------------------------------------------------------------------------------- */
+enum {
+  AIVC_MODE_CONV = 0,  /* replicate-pad(pad) + conv k x k stride s             (a1, K1, K2) */
+  AIVC_MODE_TCONV = 1, /* ConvTranspose2d k, stride 2, padding=(k+1)/2-1, output_padding 1 (a2, K3) */
+  AIVC_MODE_GDN = 2,   /* y = x / sqrt(beta + gamma . x^2)   (w = gamma_eff [C][C], bias = beta_eff) */
+  AIVC_MODE_IGDN = 3   /* y = x * sqrt(beta + gamma . x^2) */
+};
+enum {
+  AIVC_ACT_NONE = 0,
+  AIVC_ACT_LEAKY = 1,  /* v > 0 ? v : v * 0.01f */
+  AIVC_ACT_RELU = 2,   /* v > 0 ? v : 0 */
+  AIVC_ACT_SIGMOID = 3 /* 1 / (1 + fp32(det_exp(-v))) */
+};
+enum { AIVC_ALGO_AUTO = 0, AIVC_ALGO_DIRECT = 1, AIVC_ALGO_MFMA = 2 };
+
+typedef struct aivc_conv_params {
+  int32_t mode;   /* AIVC_MODE_* */
+  int32_t ksize;  /* 1, 3 or 5 (GDN modes: 1) */
+  int32_t stride; /* 1 or 2 (TCONV: must be 2 = upsampling factor) */
+  int32_t pad;    /* CONV: replicate padding on each side (0 or ksize/2); TCONV: ignored */
+  int32_t n, h_in, w_in, c_in; /* input NHWC; c_in = stored channels, multiple of 4 */
+  int32_t h_out, w_out, c_out; /* output NHWC; must match the mode's size formula */
+  int32_t act1;                /* applied to acc + bias                */
+  int32_t act2;                /* applied after the residual addition   */
+  int32_t algo;                /* AIVC_ALGO_* (AUTO picks MFMA when the shape allows) */
+  const float *x;    /* [n][h_in][w_in][c_in] */
+  const float *w;    /* [c_out][ksize][ksize][c_in]  (OHWI; TCONV: w[co][ky][kx][ci] = torch weight[ci][co][ky][kx]) */
+  const float *bias; /* [c_out] or NULL */
+  const float *mul;  /* [n][h_out][w_out][c_out] or NULL: v = mul * v (after act1) */
+  const float *res;  /* [n][h_out][w_out][c_out] or NULL: v = v + res (after mul)  */
+  float *y;          /* [n][h_out][w_out][c_out] */
+} aivc_conv_params;
+/* Epilogue order:  v = acc + bias;  [GDN: v = x / sqrtf(v) | IGDN: v = x * sqrtf(v)];
+ *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v). */
+int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
+
+/* GDN re-parameterisation, done once per layer instead of once per call:
+ *   beta_eff[i]    = max(beta[i],  beta_bound)^2  - pedestal
+ *   gamma_eff[i,j] = max(gamma[i,j], gamma_bound)^2 - pedestal       (all fp32)
+ * Replaces src/layers/misc/misc_layers.py:131-139. */
+int aivc_gdn_reparam(const float *beta, const float *gamma, int32_t c, float beta_bound,
+                     float gamma_bound, float pedestal, float *beta_eff, float *gamma_eff,
+                     aivc_stream_t stream);
+
+/* Zero-pad channels: in [npix][c_in] -> out [npix][c_out], c_out >= c_in, extra channels = 0. */
+int aivc_pad_channels(const float *in, size_t npix, int32_t c_in, float *out, int32_t c_out,
+                      aivc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Frame layout ops
+ * ---------------------------------------------------------------------------------------- */
+/* InputLayer: planar YUV 4:2:0 (fp32, values k/255) -> 3 channels of an NHWC tensor
+ * (nearest x2 on U,V, crop to the Y size).  Writes channels c_off..c_off+2 of
+ * out[n][h][w][c_store]; if zero_pad != 0 also writes 0 into channel c_off+3.
+ * u,v are [n][ceil(h/2)][ceil(w/2)].  Replaces src/layers/ae/ae_layers.py:17-35. */
+int aivc_yuv420_to_444(const float *y, const float *u, const float *v, int32_t n, int32_t h,
+                       int32_t w, float *out, int32_t c_store, int32_t c_off, int32_t zero_pad,
+                       aivc_stream_t stream);
+/* Same from 8-bit planes: value = (float)byte / 255.0f (what to_tensor() of an 8-bit PNG gives,
+ * src/func_util/img_processing.py:213-231). */
+int aivc_yuv420u8_to_444(const uint8_t *y, const uint8_t *u, const uint8_t *v, int32_t n,
+                         int32_t h, int32_t w, float *out, int32_t c_store, int32_t c_off,
+                         int32_t zero_pad, aivc_stream_t stream);
+
+/* Reconstruction tail of Decoder.decode: x_hat = x[:, :h, :w, :3] (+ skip), OutputLayer
+ * (U,V = bilinear x0.5, align_corners=False = 2x2 mean), replicate-pad U,V to ceil(h/2) x
+ * ceil(w/2), then the 8-bit cast round(255*clamp(v,0,1))/255 (half-to-even).
+ * x is [n][hx][wx][cx] with hx>=h, wx>=w, cx>=3; skip is [n][h][w][cs] (cs>=3) or NULL.
+ * Outputs (each may be NULL): fp32 planes holding 8-bit levels and/or the bytes themselves.
+ * Replaces src/real_life/decode.py:549-578, src/layers/ae/ae_layers.py:38-56,
+ *          src/func_util/img_processing.py:68-73. */
+int aivc_frame_to_yuv420(const float *x, int32_t n, int32_t hx, int32_t wx, int32_t cx,
+                         const float *skip, int32_t cs, int32_t h, int32_t w, float *y, float *u,
+                         float *v, uint8_t *y8, uint8_t *u8, uint8_t *v8, aivc_stream_t stream);
+
+/* MOFNet output unpack + bi-directional motion compensation + conditional-coding split:
+ *   alpha = clamp(m[0]+.5,0,1)  beta = clamp(m[1]+.5,0,1)  v_prev = m[2:4]  v_next = m[4:6]
+ *   frame_type P (1): beta = 1, v_next = 0
+ *   warp(x, v): bilinear sample of x at (col + v.x, row + v.y), border clamp, align_corners
+ *   x_warp = beta * warp(prev, v_prev) + (1 - beta) * warp(next, v_next)
+ *   pred   = alpha * x_warp          skip = (1 - alpha) * x_warp
+ * mof is the MOFNet synthesis output [n][hm][wm][cm] (hm>=h, wm>=w, cm>=6); prev/next are
+ * [n][h][w][cr] (cr>=3).  pred/skip/x_warp are [n][h][w][co] (co>=3, channels >=3 zeroed);
+ * alpha_out/beta_out are [n][h][w] (optional, for logging).
+ * Replaces src/real_life/decode.py:524-542,729-739 and src/func_util/optical_flow.py:14-55. */
+int aivc_warp_blend(const float *mof, int32_t hm, int32_t wm, int32_t cm, const float *prev,
+                    const float *next, int32_t cr, int32_t n, int32_t h, int32_t w,
+                    int32_t frame_type, float *pred, float *skip, float *x_warp, int32_t co,
+                    float *alpha_out, float *beta_out, aivc_stream_t stream);
+
+/* Stand-alone warp (src/func_util/optical_flow.py:14-55): x [n][h][w][c], flow [n][h][w][2]
+ * (channel 0 = horizontal, 1 = vertical, pixel units) -> out [n][h][w][c]. */
+int aivc_warp(const float *x, const float *flow, int32_t n, int32_t h, int32_t w, int32_t c,
+              float *out, aivc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Latent ops
+ * ---------------------------------------------------------------------------------------- */
+/* PdfParamParameterizer (K = 1): hs is h_s(z_hat) [n][hh][wh][2c]; crop to [h][w];
+ * mu = channels [0,c), sigma = fp32(det_exp(0.5 * clamp(channels [c,2c), -18.4207, 10))).
+ * Replaces src/layers/misc/misc_layers.py:180-219 + the crop at src/real_life/decode.py:853. */
+int aivc_hyper_params(const float *hs, int32_t n, int32_t hh, int32_t wh, int32_t c, int32_t h,
+                      int32_t w, float *mu, float *sigma, aivc_stream_t stream);
+
+/* out[p][ch] = in[p][ch] * fabsf(gain[ch])   (GainMatrix.forward, integer idx_rate;
+ * src/layers/multi_rate/gain_matrix.py:92-157).  gain may be NULL (copy). */
+int aivc_channel_gain(const float *in, const float *gain, size_t npix, int32_t c, float *out,
+                      aivc_stream_t stream);
+
+/* Encoder side: q = clamp(rint(y - mu), -256, 255) (half-to-even); y_hat = (q + mu) * |gain_dec|.
+ * mu == NULL means mu = 0 (the z latent); gain_dec == NULL means gain 1.  q (int16) and y_hat
+ * may each be NULL.  Replaces Quantizer (src/layers/misc/misc_layers.py:162-169) and the
+ * centring/gain of src/real_life/decode.py:867-885. */
+int aivc_quantize_center(const float *y, const float *mu, const float *gain_dec, size_t npix,
+                         int32_t c, int16_t *q, float *y_hat, aivc_stream_t stream);
+/* Decoder side: y_hat = ((float)q + mu) * |gain_dec|. */
+int aivc_dequantize(const int16_t *q, const float *mu, const float *gain_dec, size_t npix,
+                    int32_t c, float *y_hat, aivc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Entropy coding (torchac-compatible 32-bit range coder, 16-bit CDF precision).
+ * Replaces src/real_life/bitstream.py:82-184 (CDF build), :241-287 / :426-485 (coding) and the
+ * third-party torchac.encode_float_cdf / decode_float_cdf (fab-jul/torchac, unpinned).
+ * ---------------------------------------------------------------------------------------- */
+#define AIVC_AC_MAX_VAL 256
+#define AIVC_LP 514      /* CDF points per symbol: 2*AC_MAX_VAL + 2             */
+#define AIVC_CDF_ROW 520 /* uint16 per stored CDF row (514 used, 1040 B = 65 x 16 B) */
+#define AIVC_BALLE_PARAMS 43 /* floats per channel, see aivc_balle_cdf_table */
+#define AIVC_MAX_MAPS 256
+#define AIVC_RC_MAX_STREAMS 8
+
+/* Factorised-prior CDF table (BallePdfEstim.cdf at k - 256.5, k = 0..513), quantised like
+ * torchac:  u16 = (uint16)(rint(cdf * 65023) + k).
+ * params[c][43] = matrix_h0[1x3] h1[3x3] h2[3x3] h3[3x1] | bias_b0[3] b1[3] b2[3] b3[1] |
+ *                 bias_a0[3] a1[3] a2[3]   (row-major [d][r] for matrix_h).
+ * table is [c][AIVC_CDF_ROW]; cdf_f32 (optional) is [c][AIVC_LP].
+ * Replaces src/layers/entropy_coding/pdf_estimator.py:204-245 + src/real_life/bitstream.py:82-125. */
+int aivc_balle_cdf_table(const float *params, int32_t c, uint16_t *table, float *cdf_f32,
+                         aivc_stream_t stream);
+
+/* List of y feature maps that are not identically zero (ascending), src/real_life/bitstream.py:241-255.
+ * q is [h*w][c] int16; flags[c] gets 0/1 (device). */
+int aivc_nonzero_maps(const int16_t *q, size_t npix, int32_t c, uint8_t *flags,
+                      aivc_stream_t stream);
+
+typedef struct aivc_map_list {
+  int32_t n_maps;
+  uint8_t idx[AIVC_MAX_MAPS];
+} aivc_map_list;
+
+/* Laplace(0, sigma/sqrt(2)) CDF rows for every coded symbol position, channel-major order
+ * (stream position p = (m * npix + pix), channel = maps.idx[m]):
+ *   rows[p][k] = (uint16)(rint(cdf(k - 256.5) * 65023) + k),  k = 0..513.
+ * sigma is NHWC [npix][c].  Replaces src/real_life/bitstream.py:127-154 without ever holding
+ * the fp32 [C,H,W,514] tensor. */
+int aivc_laplace_cdf_rows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps,
+                          uint16_t *rows, aivc_stream_t stream);
+/* Encoder: only the two CDF values a symbol needs.  bounds[p] = c_lo | (c_hi << 16) with
+ * c_lo = cdf_u16[sym], c_hi = cdf_u16[sym+1], sym = q + 256. */
+int aivc_laplace_bounds(const float *sigma, const int16_t *q, size_t npix, int32_t c,
+                        const aivc_map_list *maps, uint32_t *bounds, aivc_stream_t stream);
+/* Same from a per-channel table (pmf mode, all c channels, channel-major). */
+int aivc_table_bounds(const uint16_t *table, const int16_t *q, size_t npix, int32_t c,
+                      uint32_t *bounds, aivc_stream_t stream);
+
+typedef struct aivc_rc_stream {
+  uint64_t in_off;   /* encode: first element of bounds[]; decode: byte offset of the payload
+                        in bytes[] (multiple of 4, zero padded to a multiple of 4 + 8) */
+  uint64_t out_off;  /* encode: byte offset in out[] (multiple of 4); decode: offset in sym[] */
+  uint64_t row_off;  /* decode: first row (in rows of AIVC_CDF_ROW uint16) */
+  uint32_t n_sym;
+  uint32_t in_len;   /* decode: payload length in bytes */
+  uint32_t out_cap;  /* encode: capacity in bytes at out_off */
+  uint32_t plane;    /* decode: 0 -> row = row_off + i (per-symbol rows)
+                                 P -> row = row_off + i / P (pmf table, P = h*w) */
+} aivc_rc_stream;
+typedef struct aivc_rc_batch {
+  int32_t n_streams;
+  int32_t reserved;
+  aivc_rc_stream s[AIVC_RC_MAX_STREAMS];
+} aivc_rc_batch;
+
+/* One independent range-coder stream per entry, run concurrently.
+ * encode: out_len[i] = number of bytes produced (or 0xFFFFFFFF on overflow of out_cap). */
+int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *batch, uint8_t *out,
+                      uint32_t *out_len, aivc_stream_t stream);
+/* decode: sym[out_off + i] = decoded symbol in [0, 512]. */
+int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_batch *batch,
+                      uint16_t *sym, aivc_stream_t stream);
+/* Scatter decoded symbols back to the latent: q[pix][maps.idx[m]] = sym[m*npix + pix] - 256,
+ * all other channels 0.  (src/real_life/bitstream.py:458-466) */
+int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c, const aivc_map_list *maps,
+                         int16_t *q, aivc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIVC_HIP_H */

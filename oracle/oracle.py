@@ -1,0 +1,392 @@
+"""CPU ORACLE (numpy + oracle/libaivc_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package aivc_amd/ never does.  Feature maps are numpy fp32 arrays in NHWC layout.
+
+Layer semantics restate the reference modules (paths relative to the upstream repo):
+  CustomConvLayer / UpscalingLayer / ChengResBlock / ResBlock  src/layers/misc/custom_conv_layers.py
+  GDN                                                           src/layers/misc/misc_layers.py:113-154
+  AttentionResBlock / SimplifiedAttention                       src/layers/misc/attention.py:22-97
+The networks themselves are described by plain-data "specs" (nested dicts holding numpy weights,
+see aivc_amd/models/spec.py::export_spec) so the oracle shares no code with the product modules.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from aivc_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libaivc_oracle.so')
+
+
+def build(force=False):
+    """Compile oracle/aivc_oracle.c with the committed Makefile (gcc only, no reference sources)."""
+    src = os.path.join(_HERE, 'aivc_oracle.c')
+    deps = [src, os.path.join(_HERE, '..', 'include', 'aivc_hip.h'),
+            os.path.join(_HERE, '..', 'include', 'aivc_detmath.h')]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return _LIB_PATH
+    subprocess.check_call(['make', '-C', _HERE, '-B', 'libaivc_oracle.so'],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+_fn = None
+
+
+def lib():
+    global _lib, _fn
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _fn = abi.declare(_lib, '_ref')
+    return _fn
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError('%s_ref failed: %s' % (name, abi.ERRORS.get(rc, rc)))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# primitive ops
+# ----------------------------------------------------------------------------------------------
+def pad_channels(x, c_out):
+    x = _f32(x)
+    if x.shape[-1] == c_out:
+        return x
+    out = np.empty(x.shape[:-1] + (c_out,), np.float32)
+    _chk(lib()['aivc_pad_channels'](_p(x), x.size // x.shape[-1], x.shape[-1], _p(out), c_out, None),
+         'aivc_pad_channels')
+    return out
+
+
+def pack_weight(w_oihw, c_store=None, transposed=False):
+    """torch Conv2d weight [O][I][kh][kw] (or ConvTranspose2d [I][O][kh][kw]) -> OHWI, input
+    channels zero-padded to c_store."""
+    w = np.asarray(w_oihw, np.float32)
+    if transposed:
+        w = w.transpose(1, 0, 2, 3)
+    w = w.transpose(0, 2, 3, 1)
+    if c_store is not None and c_store != w.shape[3]:
+        w = np.concatenate([w, np.zeros(w.shape[:3] + (c_store - w.shape[3],), np.float32)], axis=3)
+    return np.ascontiguousarray(w)
+
+
+def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
+           res=None):
+    x = _f32(x)
+    n, h, w_, c = x.shape
+    if c % 4:
+        x = pad_channels(x, (c + 3) // 4 * 4)
+        c = x.shape[-1]
+    w_ohwi = _f32(w_ohwi)
+    if w_ohwi.shape[3] != c:
+        w_ohwi = np.ascontiguousarray(np.concatenate(
+            [w_ohwi, np.zeros(w_ohwi.shape[:3] + (c - w_ohwi.shape[3],), np.float32)], axis=3))
+    co, k = w_ohwi.shape[0], w_ohwi.shape[1]
+    ho, wo = abi.conv_out_size(mode, h, w_, k, stride, pad)
+    y = np.empty((n, ho, wo, co), np.float32)
+    bias = None if bias is None else _f32(bias)
+    mul = None if mul is None else _f32(mul)
+    res = None if res is None else _f32(res)
+    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0,
+                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y))
+    _chk(lib()['aivc_conv2d'](C.byref(p), None), 'aivc_conv2d')
+    return y
+
+
+def gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
+    beta, gamma = _f32(beta), _f32(gamma)
+    c = beta.shape[0]
+    be, ge = np.empty(c, np.float32), np.empty((c, c), np.float32)
+    _chk(lib()['aivc_gdn_reparam'](_p(beta), _p(gamma), c, float(beta_bound), float(gamma_bound),
+                                   float(pedestal), _p(be), _p(ge), None), 'aivc_gdn_reparam')
+    return be, ge
+
+
+def gdn(x, beta_eff, gamma_eff, inverse=False, res=None):
+    c = x.shape[-1]
+    w = _f32(gamma_eff).reshape(c, 1, 1, c)
+    return conv2d(x, w, beta_eff, mode=abi.MODE_IGDN if inverse else abi.MODE_GDN, res=res)
+
+
+def yuv420_to_444(y, u, v, c_store=3, c_off=0, out=None):
+    y, u, v = _f32(y), _f32(u), _f32(v)
+    n, h, w = y.shape
+    if out is None:
+        out = np.zeros((n, h, w, c_store), np.float32)
+    _chk(lib()['aivc_yuv420_to_444'](_p(y), _p(u), _p(v), n, h, w, _p(out), out.shape[-1], c_off, 0,
+                                     None), 'aivc_yuv420_to_444')
+    return out
+
+
+def yuv420u8_to_444(y, u, v, c_store=3, c_off=0, out=None):
+    y, u, v = (np.ascontiguousarray(a, np.uint8) for a in (y, u, v))
+    n, h, w = y.shape
+    if out is None:
+        out = np.zeros((n, h, w, c_store), np.float32)
+    _chk(lib()['aivc_yuv420u8_to_444'](_p(y), _p(u), _p(v), n, h, w, _p(out), out.shape[-1], c_off,
+                                       0, None), 'aivc_yuv420u8_to_444')
+    return out
+
+
+def frame_to_yuv420(x, h, w, skip=None):
+    """returns (y, u, v) fp32 8-bit levels and (y8, u8, v8) bytes"""
+    x = _f32(x)
+    n, hx, wx, cx = x.shape
+    skip = None if skip is None else _f32(skip)
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    y, u, v = (np.empty((n, h, w), np.float32), np.empty((n, hc, wc), np.float32),
+               np.empty((n, hc, wc), np.float32))
+    y8, u8, v8 = (np.empty((n, h, w), np.uint8), np.empty((n, hc, wc), np.uint8),
+                  np.empty((n, hc, wc), np.uint8))
+    _chk(lib()['aivc_frame_to_yuv420'](_p(x), n, hx, wx, cx, _p(skip),
+                                       0 if skip is None else skip.shape[-1], h, w, _p(y), _p(u),
+                                       _p(v), _p(y8), _p(u8), _p(v8), None), 'aivc_frame_to_yuv420')
+    return (y, u, v), (y8, u8, v8)
+
+
+def warp(x, flow):
+    x, flow = _f32(x), _f32(flow)
+    n, h, w, c = x.shape
+    out = np.empty_like(x)
+    _chk(lib()['aivc_warp'](_p(x), _p(flow), n, h, w, c, _p(out), None), 'aivc_warp')
+    return out
+
+
+def warp_blend(mof, prev, nxt, h, w, frame_type, co=4):
+    mof, prev, nxt = _f32(mof), _f32(prev), _f32(nxt)
+    n, hm, wm, cm = mof.shape
+    pred = np.empty((n, h, w, co), np.float32)
+    skip = np.empty_like(pred)
+    xw = np.empty_like(pred)
+    alpha = np.empty((n, h, w), np.float32)
+    beta = np.empty((n, h, w), np.float32)
+    _chk(lib()['aivc_warp_blend'](_p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
+                                  int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha),
+                                  _p(beta), None), 'aivc_warp_blend')
+    return {'pred': pred, 'skip': skip, 'x_warp': xw, 'alpha': alpha, 'beta': beta}
+
+
+def hyper_params(hs, c, h, w):
+    hs = _f32(hs)
+    n, hh, wh, c2 = hs.shape
+    assert c2 == 2 * c
+    mu = np.empty((n, h, w, c), np.float32)
+    sigma = np.empty_like(mu)
+    _chk(lib()['aivc_hyper_params'](_p(hs), n, hh, wh, c, h, w, _p(mu), _p(sigma), None),
+         'aivc_hyper_params')
+    return mu, sigma
+
+
+def channel_gain(x, gain):
+    x = _f32(x)
+    gain = None if gain is None else _f32(gain).reshape(-1)
+    out = np.empty_like(x)
+    _chk(lib()['aivc_channel_gain'](_p(x), _p(gain), x.size // x.shape[-1], x.shape[-1], _p(out),
+                                    None), 'aivc_channel_gain')
+    return out
+
+
+def quantize_center(y, mu=None, gain_dec=None):
+    y = _f32(y)
+    mu = None if mu is None else _f32(mu)
+    gain_dec = None if gain_dec is None else _f32(gain_dec).reshape(-1)
+    q = np.empty(y.shape, np.int16)
+    y_hat = np.empty_like(y)
+    _chk(lib()['aivc_quantize_center'](_p(y), _p(mu), _p(gain_dec), y.size // y.shape[-1],
+                                       y.shape[-1], _p(q), _p(y_hat), None), 'aivc_quantize_center')
+    return q, y_hat
+
+
+def dequantize(q, mu=None, gain_dec=None):
+    q = np.ascontiguousarray(q, np.int16)
+    mu = None if mu is None else _f32(mu)
+    gain_dec = None if gain_dec is None else _f32(gain_dec).reshape(-1)
+    out = np.empty(q.shape, np.float32)
+    _chk(lib()['aivc_dequantize'](_p(q), _p(mu), _p(gain_dec), q.size // q.shape[-1], q.shape[-1],
+                                  _p(out), None), 'aivc_dequantize')
+    return out
+
+
+def pack_balle_params(matrix_h, bias_b, bias_a):
+    """lists of numpy arrays as in BallePdfEstim: matrix_h [C,1,3],[C,3,3],[C,3,3],[C,3,1];
+    bias_b [C,3]x3,[C,1]; bias_a [C,3]x3  ->  [C][43]"""
+    c = matrix_h[0].shape[0]
+    parts = [np.asarray(m, np.float32).reshape(c, -1) for m in matrix_h]
+    parts += [np.asarray(b, np.float32).reshape(c, -1) for b in bias_b]
+    parts += [np.asarray(a, np.float32).reshape(c, -1) for a in bias_a]
+    out = np.ascontiguousarray(np.concatenate(parts, axis=1), np.float32)
+    assert out.shape[1] == abi.BALLE_PARAMS
+    return out
+
+
+def balle_cdf_table(params):
+    params = _f32(params)
+    c = params.shape[0]
+    table = np.empty((c, abi.CDF_ROW), np.uint16)
+    cdf = np.empty((c, abi.LP), np.float32)
+    _chk(lib()['aivc_balle_cdf_table'](_p(params), c, _p(table), _p(cdf), None),
+         'aivc_balle_cdf_table')
+    return table, cdf
+
+
+def nonzero_maps(q):
+    q = np.ascontiguousarray(q, np.int16)
+    c = q.shape[-1]
+    flags = np.empty(c, np.uint8)
+    _chk(lib()['aivc_nonzero_maps'](_p(q), q.size // c, c, _p(flags), None), 'aivc_nonzero_maps')
+    return [i for i in range(c) if flags[i]]
+
+
+def laplace_cdf_rows(sigma, maps):
+    sigma = _f32(sigma)
+    c = sigma.shape[-1]
+    npix = sigma.size // c
+    ml = abi.MapList.make(maps)
+    rows = np.empty((len(maps) * npix, abi.CDF_ROW), np.uint16)
+    _chk(lib()['aivc_laplace_cdf_rows'](_p(sigma), npix, c, C.byref(ml), _p(rows), None),
+         'aivc_laplace_cdf_rows')
+    return rows
+
+
+def laplace_bounds(sigma, q, maps):
+    sigma = _f32(sigma)
+    q = np.ascontiguousarray(q, np.int16)
+    c = sigma.shape[-1]
+    npix = sigma.size // c
+    ml = abi.MapList.make(maps)
+    bounds = np.empty(len(maps) * npix, np.uint32)
+    _chk(lib()['aivc_laplace_bounds'](_p(sigma), _p(q), npix, c, C.byref(ml), _p(bounds), None),
+         'aivc_laplace_bounds')
+    return bounds
+
+
+def table_bounds(table, q):
+    table = np.ascontiguousarray(table, np.uint16)
+    q = np.ascontiguousarray(q, np.int16)
+    c = q.shape[-1]
+    npix = q.size // c
+    bounds = np.empty(c * npix, np.uint32)
+    _chk(lib()['aivc_table_bounds'](_p(table), _p(q), npix, c, _p(bounds), None),
+         'aivc_table_bounds')
+    return bounds
+
+
+def range_encode(bounds):
+    """one stream -> bytes"""
+    bounds = np.ascontiguousarray(bounds, np.uint32)
+    cap = 16 + bounds.size * 3
+    out = np.zeros(cap, np.uint8)
+    out_len = np.zeros(1, np.uint32)
+    b = abi.RcBatch()
+    b.n_streams = 1
+    b.s[0].in_off, b.s[0].out_off, b.s[0].n_sym, b.s[0].out_cap = 0, 0, bounds.size, cap
+    _chk(lib()['aivc_range_encode'](_p(bounds), C.byref(b), _p(out), _p(out_len), None),
+         'aivc_range_encode')
+    assert out_len[0] != 0xFFFFFFFF
+    return out[:out_len[0]].tobytes()
+
+
+def range_decode(payload, rows, n_sym, plane=0):
+    """rows: [n_rows][CDF_ROW] uint16; plane=0 -> one row per symbol, else row = i // plane"""
+    rows = np.ascontiguousarray(rows, np.uint16)
+    buf = np.frombuffer(payload, np.uint8)
+    padded = np.zeros((len(buf) + 3) // 4 * 4 + 8, np.uint8)
+    padded[:len(buf)] = buf
+    sym = np.empty(n_sym, np.uint16)
+    b = abi.RcBatch()
+    b.n_streams = 1
+    s = b.s[0]
+    s.in_off, s.out_off, s.row_off, s.n_sym, s.in_len, s.plane = 0, 0, 0, n_sym, len(buf), plane
+    _chk(lib()['aivc_range_decode'](_p(padded), _p(rows), C.byref(b), _p(sym), None),
+         'aivc_range_decode')
+    return sym
+
+
+def scatter_symbols(sym, npix, c, maps):
+    sym = np.ascontiguousarray(sym, np.uint16)
+    q = np.empty((npix, c), np.int16)
+    ml = abi.MapList.make(maps)
+    _chk(lib()['aivc_scatter_symbols'](_p(sym), npix, c, C.byref(ml), _p(q), None),
+         'aivc_scatter_symbols')
+    return q
+
+
+# ----------------------------------------------------------------------------------------------
+# layers (specs are nested dicts; x is NHWC)
+# ----------------------------------------------------------------------------------------------
+_ACT = {'no': abi.ACT_NONE, None: abi.ACT_NONE, 'leaky_relu': abi.ACT_LEAKY, 'relu': abi.ACT_RELU,
+        'sigmoid': abi.ACT_SIGMOID}
+
+
+def _gdn_from_spec(g, x, res=None):
+    be, ge = gdn_reparam(g['beta'], g['gamma'], g['beta_bound'], g['gamma_bound'], g['pedestal'])
+    return gdn(x, be, ge, inverse=g['inverse'], res=res)
+
+
+def run_layer(spec, x, res=None):
+    """Evaluate one layer spec.  `res` (optional) is added to the output (used by the residual
+    blocks to express `aux(x) + layers(x)` with the same operand order as the fused kernels)."""
+    t = spec['type']
+    if t == 'Sequential':
+        for s in spec['layers'][:-1]:
+            x = run_layer(s, x)
+        return run_layer(spec['layers'][-1], x, res=res) if spec['layers'] else x
+    if t == 'CustomConvLayer':  # custom_conv_layers.py:129-180
+        k = spec['k']
+        w = pack_weight(spec['weight'])
+        nl = spec['nl']
+        if nl in ('gdn', 'gdn_inverse'):
+            y = conv2d(x, w, spec.get('bias'), stride=spec['stride'], pad=k // 2)
+            return _gdn_from_spec(spec['gdn'], y, res=res)
+        return conv2d(x, w, spec.get('bias'), stride=spec['stride'], pad=k // 2, act1=_ACT[nl],
+                      res=res)
+    if t == 'UpscalingLayer':  # custom_conv_layers.py:183-253
+        w = pack_weight(spec['weight'], transposed=True)
+        nl = spec['nl']
+        if nl in ('gdn', 'gdn_inverse'):
+            y = conv2d(x, w, spec.get('bias'), mode=abi.MODE_TCONV, stride=2)
+            return _gdn_from_spec(spec['gdn'], y, res=res)
+        return conv2d(x, w, spec.get('bias'), mode=abi.MODE_TCONV, stride=2, act1=_ACT[nl], res=res)
+    if t == 'Conv2d':  # bare nn.Conv2d (1x1 in the attention blocks / the s2 skip of ChengResBlock)
+        return conv2d(x, pack_weight(spec['weight']), spec.get('bias'), stride=spec['stride'], pad=0,
+                      act1=_ACT[spec.get('nl')], res=res, mul=spec.get('_mul'))
+    if t == 'ChengResBlock':  # custom_conv_layers.py:21-109
+        if spec['mode'] == 'plain':
+            return run_layer(spec['layers'], x, res=x)  # x + layers(x)
+        aux = run_layer(spec['aux'], x)
+        return run_layer(spec['layers'], x, res=aux)  # aux(x) + layers(x)
+    if t == 'ResBlock':  # custom_conv_layers.py:112-126 : relu(x + conv(relu(conv(x))))
+        k = spec['k']
+        h = conv2d(x, pack_weight(spec['w1']), spec['b1'], pad=k // 2, act1=abi.ACT_RELU)
+        return conv2d(h, pack_weight(spec['w2']), spec['b2'], pad=k // 2, res=x, act2=abi.ACT_RELU)
+    if t == 'AttentionResBlock':  # attention.py:22-42 : leaky(x + c1x1(leaky(c3x3(leaky(c1x1(x))))))
+        h = conv2d(x, pack_weight(spec['w1']), spec['b1'], act1=abi.ACT_LEAKY)
+        h = conv2d(h, pack_weight(spec['w2']), spec['b2'], pad=1, act1=abi.ACT_LEAKY)
+        return conv2d(h, pack_weight(spec['w3']), spec['b3'], res=x, act2=abi.ACT_LEAKY)
+    if t == 'SimplifiedAttention':  # attention.py:45-97 : trunk(x) * sigmoid(conv1x1(att(x))) + x
+        trunk = x
+        for s in spec['trunk']:
+            trunk = run_layer(s, trunk)
+        att = x
+        for s in spec['attention']:
+            att = run_layer(s, att)
+        return conv2d(att, pack_weight(spec['w_out']), spec['b_out'], act1=abi.ACT_SIGMOID,
+                      mul=trunk, res=x)
+    raise ValueError('unknown layer spec type %r' % t)

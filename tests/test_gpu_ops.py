@@ -1,0 +1,199 @@
+"""HIP kernels vs the CPU oracle, through the C ABI, on seeded inputs: bit exact."""
+import numpy as np
+import pytest
+import torch
+
+from aivc_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def eq(a_gpu, b_np):
+    a = a_gpu.cpu().numpy()
+    if a.dtype == np.int16 and b_np.dtype == np.uint16:
+        a = a.view(np.uint16)
+    if a.dtype == np.int32 and b_np.dtype == np.uint32:
+        a = a.view(np.uint32)
+    assert a.shape == b_np.shape
+    np.testing.assert_array_equal(a, b_np)
+
+
+CONV_CASES = [
+    # mode, k, stride, pad, cin, cout, h, w, act1, act2, mul, res
+    (abi.MODE_CONV, 5, 2, 2, 4, 8, 17, 23, 0, 0, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 8, 8, 9, 11, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_CONV, 3, 2, 1, 12, 16, 10, 14, abi.ACT_RELU, 0, False, False),
+    (abi.MODE_CONV, 1, 2, 0, 8, 8, 9, 13, 0, 0, False, False),
+    (abi.MODE_CONV, 1, 1, 0, 8, 8, 6, 10, abi.ACT_SIGMOID, 0, True, True),
+    (abi.MODE_CONV, 3, 1, 1, 8, 8, 7, 9, 0, abi.ACT_RELU, False, True),
+    (abi.MODE_TCONV, 5, 2, 0, 8, 6, 7, 9, 0, 0, False, False),
+    (abi.MODE_TCONV, 3, 2, 0, 8, 8, 5, 6, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_TCONV, 5, 2, 0, 64, 3, 6, 5, 0, 0, False, False),
+    (abi.MODE_GDN, 1, 1, 0, 8, 8, 5, 7, 0, 0, False, False),
+    (abi.MODE_IGDN, 1, 1, 0, 16, 16, 5, 7, 0, 0, False, True),
+    (abi.MODE_CONV, 5, 2, 2, 64, 128, 33, 47, 0, 0, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 128, 128, 19, 21, abi.ACT_LEAKY, 0, False, True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('algo', [abi.ALGO_DIRECT, abi.ALGO_AUTO])
+def test_conv_family_bit_exact(case, algo, oracle, cuda):
+    from aivc_amd import ops
+    mode, k, s, pad, ci, co, h, w, a1, a2, use_mul, use_res = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((2, h, w, ci), dtype=np.float32)
+    wt = (rng.standard_normal((co, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)
+    bias = rng.standard_normal(co, dtype=np.float32)
+    if mode in (abi.MODE_GDN, abi.MODE_IGDN):
+        wt = np.abs(wt) * 0.1
+        bias = np.abs(bias) + 0.1
+    ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+    mul = rng.standard_normal((2, ho, wo, co), dtype=np.float32) if use_mul else None
+    res = rng.standard_normal((2, ho, wo, co), dtype=np.float32) if use_res else None
+    ref = oracle.conv2d(x, wt, bias, mode=mode, stride=s, pad=pad, act1=a1, act2=a2, mul=mul, res=res)
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(bias, cuda), mode=mode, stride=s, pad=pad, act1=a1, act2=a2,
+                     mul=None if mul is None else T(mul, cuda), res=None if res is None else T(res, cuda),
+                     algo=algo)
+    eq(got, ref)
+
+
+def test_frame_ops_bit_exact(oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(5)
+    for (h, w) in [(9, 13), (10, 14), (16, 16), (1, 1)]:
+        hc, wc = (h + 1) // 2, (w + 1) // 2
+        y8 = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+        u8 = rng.integers(0, 256, (2, hc, wc), dtype=np.uint8)
+        v8 = rng.integers(0, 256, (2, hc, wc), dtype=np.uint8)
+        eq(ops.yuv420_to_444(T(y8, cuda), T(u8, cuda), T(v8, cuda), c_store=4),
+           oracle.yuv420u8_to_444(y8, u8, v8, c_store=4))
+        yf, uf, vf = (a.astype(np.float32) / np.float32(255) for a in (y8, u8, v8))
+        eq(ops.yuv420_to_444(T(yf, cuda), T(uf, cuda), T(vf, cuda), c_store=4),
+           oracle.yuv420_to_444(yf, uf, vf, c_store=4))
+        x = (rng.standard_normal((2, h + 3, w + 2, 4), dtype=np.float32) * 0.4 + 0.5).astype(np.float32)
+        skip = (rng.standard_normal((2, h, w, 4), dtype=np.float32) * 0.1).astype(np.float32)
+        for sk in (None, skip):
+            rf, rb = oracle.frame_to_yuv420(x, h, w, skip=sk)
+            gf, gb = ops.frame_to_yuv420(T(x, cuda), h, w, skip=None if sk is None else T(sk, cuda))
+            for a, b in zip(gf + gb, rf + rb):
+                eq(a, b)
+
+
+def test_warp_bit_exact(oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(6)
+    for (h, w, s) in [(9, 13, 3.0), (8, 8, 30.0), (5, 1, 2.0), (32, 48, 1.0)]:
+        x = rng.standard_normal((2, h, w, 4), dtype=np.float32)
+        flow = (rng.standard_normal((2, h, w, 2), dtype=np.float32) * s).astype(np.float32)
+        eq(ops.warp(T(x, cuda), T(flow, cuda)), oracle.warp(x, flow))
+        mof = (rng.standard_normal((2, h + 2, w + 1, 8), dtype=np.float32)).astype(np.float32)
+        mof[..., 2:6] *= s
+        prev = rng.random((2, h, w, 4), dtype=np.float32)
+        nxt = rng.random((2, h, w, 4), dtype=np.float32)
+        for ft in (1, 2):
+            r = oracle.warp_blend(mof, prev, nxt, h, w, ft)
+            g = ops.warp_blend(T(mof, cuda), T(prev, cuda), T(nxt, cuda), h, w, ft, want_aux=True)
+            for kk in ('pred', 'skip', 'x_warp', 'alpha', 'beta'):
+                eq(g[kk], r[kk])
+
+
+def test_latent_ops_bit_exact(oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(7)
+    hs = (rng.standard_normal((1, 6, 9, 16), dtype=np.float32) * 8).astype(np.float32)
+    hs[0, 0, 0, 8], hs[0, 0, 1, 8] = -30, 30
+    mu, sg = oracle.hyper_params(hs, 8, 5, 7)
+    gmu, gsg = ops.hyper_params(T(hs, cuda), 8, 5, 7)
+    eq(gmu, mu)
+    eq(gsg, sg)
+    y = (rng.standard_normal((1, 5, 7, 8), dtype=np.float32) * 20).astype(np.float32)
+    y[0, 0, 0, :4] = [0.5, 1.5, 2.5, -0.5]
+    y[0, 0, 1, :2] = [400, -400]
+    gain = rng.standard_normal(8).astype(np.float32)
+    eq(ops.channel_gain(T(y, cuda), T(gain, cuda)), oracle.channel_gain(y, gain))
+    q, yh = oracle.quantize_center(y, mu, gain)
+    gq, gyh = ops.quantize_center(T(y, cuda), T(mu, cuda), T(gain, cuda))
+    eq(gq, q)
+    eq(gyh, yh)
+    q0, yh0 = oracle.quantize_center(y)
+    gq0, gyh0 = ops.quantize_center(T(y, cuda))
+    eq(gq0, q0)
+    eq(gyh0, yh0)
+    eq(ops.dequantize(T(q, cuda), T(mu, cuda), T(gain, cuda)), oracle.dequantize(q, mu, gain))
+    beta = np.abs(rng.standard_normal(8)).astype(np.float32)
+    gamma = (rng.standard_normal((8, 8)) * 0.1).astype(np.float32)
+    be, ge = oracle.gdn_reparam(beta, gamma, 1e-3, 2 ** -18, 2 ** -36)
+    gbe, gge = ops.gdn_reparam(T(beta, cuda), T(gamma, cuda), 1e-3, 2 ** -18, 2 ** -36)
+    eq(gbe, be)
+    eq(gge, ge)
+
+
+def test_cdf_kernels_bit_exact(oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(8)
+    params = (rng.standard_normal((6, abi.BALLE_PARAMS)) * 1.2).astype(np.float32)
+    table, cdf = oracle.balle_cdf_table(params)
+    gt, gc = ops.balle_cdf_table(T(params, cuda), want_float=True)
+    eq(gc, cdf)
+    eq(gt, table)
+    sig = np.exp(rng.uniform(np.log(1e-4), np.log(148.4), (1, 6, 7, 8))).astype(np.float32)
+    sig[0, 0, 0, 0], sig[0, 0, 0, 1] = 1e-4, 148.41316
+    maps = [0, 2, 3, 7]
+    eq(ops.laplace_cdf_rows(T(sig, cuda), maps), oracle.laplace_cdf_rows(sig, maps))
+    q = np.clip(np.rint(rng.laplace(0, 1, sig.shape) * sig), -256, 255).astype(np.int16)
+    eq(ops.laplace_bounds(T(sig, cuda), T(q, cuda), maps), oracle.laplace_bounds(sig, q, maps))
+    qz = rng.integers(-5, 6, (1, 3, 4, 6)).astype(np.int16)
+    eq(ops.table_bounds(T(table.view(np.int16), cuda), T(qz, cuda)), oracle.table_bounds(table, qz))
+    flags = ops.nonzero_flags(T(q, cuda)).cpu().numpy()
+    assert [i for i in range(8) if flags[i]] == oracle.nonzero_maps(q)
+
+
+@pytest.mark.parametrize('n_sym,scale', [(1, 1.0), (63, 0.3), (64, 2.0), (65, 5.0), (1000, 0.05), (5000, 1.0),
+                                         (20000, 40.0), (3000, 1e-4)])
+def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(n_sym)
+    c = 4
+    npix = (n_sym + c - 1) // c
+    sig = (np.exp(rng.uniform(np.log(0.05), np.log(4.0), (1, 1, npix, c))) * scale).astype(np.float32)
+    sig = np.clip(sig, 1e-4, 148.4).astype(np.float32)
+    q = np.clip(np.rint(rng.laplace(0, 1, sig.shape) * sig / np.sqrt(2)), -256, 255).astype(np.int16)
+    maps = list(range(c))
+    bounds = oracle.laplace_bounds(sig, q, maps)[:n_sym]
+    ref_bytes = oracle.range_encode(bounds)
+    out, lens, offs = ops.range_encode([T(bounds.view(np.int32), cuda)])
+    ln = int(lens.cpu()[0])
+    got_bytes = out.cpu().numpy()[:ln].tobytes()
+    assert got_bytes == ref_bytes
+    rows = oracle.laplace_cdf_rows(sig, maps)[:n_sym]
+    ref_sym = oracle.range_decode(ref_bytes, rows, n_sym)
+    want = (q.reshape(-1, c).T.reshape(-1)[:n_sym].astype(np.int32) + 256).astype(np.uint16)
+    np.testing.assert_array_equal(ref_sym, want)
+    got_sym = ops.range_decode([ref_bytes], [T(rows.view(np.int16), cuda)], [n_sym], [0])[0]
+    eq(got_sym, ref_sym)
+
+
+def test_range_coder_pmf_and_scatter(oracle, cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(11)
+    params = (rng.standard_normal((5, abi.BALLE_PARAMS)) * 0.8).astype(np.float32)
+    table, _ = oracle.balle_cdf_table(params)
+    qz = rng.integers(-3, 4, (1, 6, 7, 5)).astype(np.int16)
+    bounds = oracle.table_bounds(table, qz)
+    ref_bytes = oracle.range_encode(bounds)
+    out, lens, _ = ops.range_encode([T(bounds.view(np.int32), cuda)])
+    assert out.cpu().numpy()[:int(lens.cpu()[0])].tobytes() == ref_bytes
+    n_sym = qz.size
+    sym = ops.range_decode([ref_bytes], [T(table.view(np.int16), cuda)], [n_sym], [42])[0]
+    eq(sym, oracle.range_decode(ref_bytes, table, n_sym, plane=42))
+    qback = ops.scatter_symbols(sym, 42, 5, list(range(5)))
+    eq(qback, qz.reshape(42, 5))
+    # partial map list
+    maps = [1, 4]
+    s2 = T((qz.reshape(42, 5)[:, maps].T.reshape(-1).astype(np.int32) + 256).astype(np.uint16).view(np.int16), cuda)
+    eq(ops.scatter_symbols(s2, 42, 5, maps), oracle.scatter_symbols(s2.cpu().numpy().view(np.uint16), 42, 5, maps))
