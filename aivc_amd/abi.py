@@ -69,6 +69,7 @@ PROTOTYPES = {
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_frame_to_yuv420': [_f, _i32, _i32, _i32, _i32, _f, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f],
+    'aivc_downsample2x': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'aivc_warp_blend': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],
     'aivc_warp': [_f, _f, _i32, _i32, _i32, _i32, _f],
     'aivc_hyper_params': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f],

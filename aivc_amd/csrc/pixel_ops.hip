@@ -99,6 +99,19 @@ __global__ __launch_bounds__(256) void frame_to_yuv420_kernel(RecArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void downsample2x_kernel(const float *__restrict__ x, int n, int h, int w, int c,
+                                                           int ch0, int nch, float *__restrict__ out) {
+  const int hf = h / 2, wf = w / 2;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n * nch * hf * wf) return;
+  const int q = (int)(gid % wf), r = (int)((gid / wf) % hf);
+  const int j = (int)((gid / ((size_t)wf * hf)) % nch), b = (int)(gid / ((size_t)wf * hf * nch));
+  const float *p00 = x + (((size_t)b * h + 2 * r) * w + 2 * q) * c + ch0 + j;
+  const float top = 0.5f * p00[0] + 0.5f * p00[c];
+  const float bot = 0.5f * p00[(size_t)w * c] + 0.5f * p00[(size_t)w * c + c];
+  out[gid] = 0.5f * top + 0.5f * bot;
+}
+
 // ---------------------------------------------------------------- warp (grid_sample bilinear/border)
 __device__ __forceinline__ float warp_coord(float pos, int size) {
   const int d = size - 1 > 1 ? size - 1 : 1;
@@ -319,6 +332,16 @@ AIVC_EXPORT int aivc_frame_to_yuv420(const float *x, int32_t n, int32_t hx, int3
   const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2);
   hipLaunchKernelGGL(frame_to_yuv420_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), a);
   return check_launch("frame_to_yuv420");
+}
+
+AIVC_EXPORT int aivc_downsample2x(const float *x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ch0,
+                                  int32_t nch, float *out, aivc_stream_t stream) {
+  if (!x || !out || n <= 0 || h <= 0 || w <= 0 || ch0 < 0 || nch <= 0 || ch0 + nch > c) return AIVC_ERR_ARG;
+  const size_t total = (size_t)n * nch * (h / 2) * (w / 2);
+  if (total == 0) return AIVC_OK;
+  hipLaunchKernelGGL(downsample2x_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), x, n, h, w, c, ch0,
+                     nch, out);
+  return check_launch("downsample2x");
 }
 
 AIVC_EXPORT int aivc_warp(const float *x, const float *flow, int32_t n, int32_t h, int32_t w, int32_t c, float *out,

@@ -1,0 +1,21 @@
+"""Per-module cache of kernel-ready (packed, device-resident) parameters.  Kept outside the modules
+so that pickles stay identical to the reference's (a loaded reference pickle has no such state)."""
+import weakref
+
+_CACHE = weakref.WeakKeyDictionary()
+
+
+def cached(module, key, params, builder):
+    """builder() is re-run whenever one of `params` was modified in place or moved."""
+    slot = _CACHE.setdefault(module, {})
+    stamp = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+    hit = slot.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    val = builder()
+    slot[key] = (stamp, val)
+    return val
+
+
+def clear():
+    _CACHE.clear()

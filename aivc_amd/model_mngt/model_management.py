@@ -1,0 +1,81 @@
+"""load_model / infer_one_sequence / infer_one_GOP with the reference's signatures
+(src/model_mngt/model_management.py)."""
+import math
+import os
+
+import torch
+
+from ..func_util.console_display import print_log_msg
+from ..func_util.nn_util import get_value
+from ..real_life.bitstream import ArithmeticCoder
+from ..real_life.cat_binary_files import cat_one_video
+
+
+def attach_arithmetic_coders(model, device=None):
+    """src/model_mngt/model_management.py:349-359: the coders are not pickled, they are attached
+    after loading."""
+    for net in (model.codec_net.codec_net, model.mode_net.mode_net):
+        net.ac = ArithmeticCoder({'balle_pdf_estim_z': net.pdf_z, 'device': device})
+    return model
+
+
+def load_model(prefix='', on_cpu=False):
+    """torch.load of a full-module pickle './<prefix>model.pt' (reference pickles resolve their
+    classes here through aivc_amd.install_aliases())."""
+    import aivc_amd
+    aivc_amd.install_aliases()
+    map_loc = torch.device('cpu') if on_cpu else None
+    model = torch.load('./' + prefix + 'model.pt', map_location=map_loc, weights_only=False)
+    return attach_arithmetic_coders(model, map_loc)
+
+
+def infer_one_GOP(param):
+    default = {'model': None, 'GOP_struct': None, 'GOP_struct_name': None, 'raw_frames': None, 'l_codec': 0.,
+               'l_mof': 0., 'index_GOP_in_video': 0, 'generate_bitstream': False, 'bitstream_dir': '',
+               'real_idx_first_frame': 0, 'idx_rate': 0., 'flag_bitstream_debug': False}
+    model = get_value('model', param, default).eval()
+    keys = ('GOP_struct', 'GOP_struct_name', 'raw_frames', 'idx_rate', 'index_GOP_in_video',
+            'generate_bitstream', 'real_idx_first_frame', 'bitstream_dir', 'flag_bitstream_debug')
+    with torch.no_grad():
+        net_out = model.GOP_forward({k: get_value(k, param, default) for k in keys})
+    # x_hat is already cropped to the frame size and cast to 8-bit levels by the reconstruction kernel
+    result = {f: {'size_bytes': float(sum(net_out[f][k].item() for k in
+                                          ('mode_rate_y', 'mode_rate_z', 'codec_rate_y', 'codec_rate_z')) / 8)}
+              for f in net_out}
+    return net_out, result
+
+
+def infer_one_sequence(param):
+    """GOP loop over a PNG-triplet directory is replaced by direct planar input: `raw_video` is a
+    list of YUV dicts (float levels or uint8) for frames idx_starting_frame..idx_end_frame."""
+    default = {'model': None, 'GOP_struct': None, 'GOP_struct_name': None, 'raw_video': None,
+               'idx_starting_frame': 0, 'idx_end_frame': 8, 'generate_bitstream': False, 'bitstream_dir': '',
+               'idx_rate': 0., 'flag_bitstream_debug': False, 'final_bitstream_path': ''}
+    model = get_value('model', param, default)
+    gop = get_value('GOP_struct', param, default)
+    gop_name = get_value('GOP_struct_name', param, default)
+    video = get_value('raw_video', param, default)
+    first = get_value('idx_starting_frame', param, default)
+    last = get_value('idx_end_frame', param, default)
+    gen = get_value('generate_bitstream', param, default)
+    bdir = get_value('bitstream_dir', param, default)
+    nb_frames = last - first + 1
+    unit = len(gop)
+    nb_gop = math.ceil(nb_frames / unit)
+    print_log_msg('DEBUG', 'infer_one_sequence', 'nb_GOP', nb_gop)
+    if gen:
+        bdir = bdir if bdir.endswith('/') else bdir + '/'
+        os.makedirs(bdir, exist_ok=True)
+    seq = {}
+    for i in range(nb_gop):
+        raw = {'frame_%d' % f: video[min(i * unit + f, nb_frames - 1)] for f in range(unit)}
+        _, res = infer_one_GOP({'model': model, 'GOP_struct': gop, 'GOP_struct_name': gop_name, 'raw_frames': raw,
+                                'index_GOP_in_video': i, 'generate_bitstream': gen, 'bitstream_dir': bdir,
+                                'real_idx_first_frame': i * unit + first,
+                                'idx_rate': get_value('idx_rate', param, default)})
+        for f in range(unit):
+            seq['frame_%d' % (i * unit + f + first)] = res['frame_%d' % f]
+    if gen:
+        cat_one_video({'bitstream_dir': bdir, 'idx_starting_frame': first, 'idx_end_frame': last,
+                       'final_bitstream_path': get_value('final_bitstream_path', param, default)})
+    return seq

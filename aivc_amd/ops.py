@@ -150,6 +150,15 @@ def frame_to_yuv420(x, h, w, skip=None, want_float=True, want_u8=True):
     return tuple(f), tuple(b)
 
 
+def downsample2x(x, ch0, nch):
+    """NHWC x -> planar [n, nch, h//2, w//2] 2x2 means of channels ch0..ch0+nch-1 (OutputLayer)."""
+    x = _dev(x, torch.float32, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty((n, nch, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    call('aivc_downsample2x', _p(x), n, h, w, c, ch0, nch, _p(out), _stream())
+    return out
+
+
 def warp(x, flow):
     x, flow = _dev(x, torch.float32, 'x'), _dev(flow, torch.float32, 'flow')
     n, h, w, c = x.shape

@@ -137,6 +137,12 @@ int aivc_frame_to_yuv420(const float *x, int32_t n, int32_t hx, int32_t wx, int3
                          const float *skip, int32_t cs, int32_t h, int32_t w, float *y, float *u,
                          float *v, uint8_t *y8, uint8_t *u8, uint8_t *v8, aivc_stream_t stream);
 
+/* OutputLayer alone (no cast): out[n][j][h/2][w/2] = 2x2 mean of channel ch0+j of x [n][h][w][c]
+ * with the bilinear x0.5 operation order  0.5*(0.5*a + 0.5*b) + 0.5*(0.5*c + 0.5*d).
+ * Replaces F.interpolate(scale_factor=0.5, mode='bilinear') at src/layers/ae/ae_layers.py:46-52. */
+int aivc_downsample2x(const float *x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ch0,
+                      int32_t nch, float *out, aivc_stream_t stream);
+
 /* MOFNet output unpack + bi-directional motion compensation + conditional-coding split:
  *   alpha = clamp(m[0]+.5,0,1)  beta = clamp(m[1]+.5,0,1)  v_prev = m[2:4]  v_next = m[4:6]
  *   frame_type P (1): beta = 1, v_next = 0

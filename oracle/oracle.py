@@ -42,8 +42,11 @@ _fn = None
 def lib():
     global _lib, _fn
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        try:
+            build()  # no-op when the .so is newer than its sources
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(_LIB_PATH):
+                raise
         _lib = C.CDLL(_LIB_PATH)
         _fn = abi.declare(_lib, '_ref')
     return _fn
@@ -159,6 +162,14 @@ def frame_to_yuv420(x, h, w, skip=None):
                                        0 if skip is None else skip.shape[-1], h, w, _p(y), _p(u),
                                        _p(v), _p(y8), _p(u8), _p(v8), None), 'aivc_frame_to_yuv420')
     return (y, u, v), (y8, u8, v8)
+
+
+def downsample2x(x, ch0, nch):
+    x = _f32(x)
+    n, h, w, c = x.shape
+    out = np.empty((n, nch, h // 2, w // 2), np.float32)
+    _chk(lib()['aivc_downsample2x'](_p(x), n, h, w, c, ch0, nch, _p(out), None), 'aivc_downsample2x')
+    return out
 
 
 def warp(x, flow):
