@@ -1,6 +1,310 @@
-// conv_mfma.hip -- placeholder until the MFMA implicit-GEMM kernels land (next milestone).
+// conv_mfma.hip -- implicit-GEMM convolution family on the gfx950 matrix cores, exact fp32.
+//
+//   GEMM view      M = output pixels (n, oy, ox), N = output channels, K = (ky, kx, ci)
+//   instruction    v_mfma_f32_32x32x2_f32: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), a k-ordered fp32
+//                  fmaf chain, so chaining MFMAs along ascending K reproduces bit for bit the scalar
+//                  kernels / CPU oracle (no split-K, no atomics, one accumulator per output).
+//   roofline       fp32 MFMA = 157.3 TFLOP/s dense (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz).
+//   data layout    activations NHWC, weights OHWI: a K-slice of one pixel / one output channel is a
+//                  contiguous run of floats -> every global access is a 16-byte load.
+//   staging        global -> registers (issued one K-tile ahead, in flight during the MFMAs) ->
+//                  LDS (one buffer, 2 barriers per K-tile; 2-3 workgroups per CU hide them).
+//                  LDS rows hold BK = 32 K-values (+4 pad -> conflict-free ds_read_b128).  Inside
+//                  each group of 8 consecutive K the even ks are stored first, then the odd ks:
+//                  lane half h = lane>>5 of the MFMA needs k = 2j + h, so one ds_read_b128 at
+//                  column 8*o + 4*h yields its operand for 4 consecutive MFMA steps.
+//   im2col         done in the loader's address arithmetic: replicate padding = clamp of the input
+//                  coordinate; transposed conv = 4 output-parity classes (blockIdx.z), each a small
+//                  dense conv over the taps of that parity with zero fill outside the image.
+//   epilogue       bias / GDN division / activation / gate / residual fused, straight from the
+//                  accumulators (lanes 0-31 of a row write 128 contiguous bytes).
 #include "common.h"
+
 namespace aivc {
-bool conv2d_mfma_supported(const aivc_conv_params &) { return false; }
-int conv2d_mfma(const aivc_conv_params &, hipStream_t) { return AIVC_ERR_UNSUPPORTED; }
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct MfmaArgs {
+  aivc_conv_params p;
+  int M;               // GEMM rows per z-slice
+  uint32_t cin_magic;  // ceil(2^32 / c_in): k / c_in == (k * magic) >> 32 for k < 2^16
+};
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int UA = BM * 4 / 256;          // (row, octet) units per thread for A
+  constexpr int UB = (BN * 4 + 255) / 256;  // ... for B
+  constexpr bool TCONV = MODE == AIVC_MODE_TCONV;
+  constexpr bool GDN = MODE == AIVC_MODE_GDN;  // covers IGDN (runtime mode in the epilogue)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;
+  float *Bs = smem + BM * LDS_STRIDE;
+
+  const aivc_conv_params &p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ks = p.ksize, Cin = p.c_in, H = p.h_in, W = p.w_in, Cout = p.c_out;
+  const int M = a.M;
+
+  int pyc = 0, pxc = 0, ky0 = 0, kx0 = 0, nky = ks, nkx = ks, tpad = 0;
+  if (TCONV) {
+    tpad = (ks + 1) / 2 - 1;
+    pyc = blockIdx.z >> 1;
+    pxc = blockIdx.z & 1;
+    ky0 = (pyc + tpad) & 1;
+    kx0 = (pxc + tpad) & 1;
+    nky = (ks - ky0 + 1) / 2;
+    nkx = (ks - kx0 + 1) / 2;
+  }
+  const int K = nky * nkx * Cin;
+  const int nkt = (K + BK - 1) / BK;
+  const bool fast = (Cin % BK) == 0;  // a K-tile never straddles two taps
+  const uint32_t inv_nkx = (65536u + nkx - 1) / nkx;
+
+  // ---- per-thread loader units ------------------------------------------------------------
+  int a_by[UA], a_bx[UA];
+  uint32_t a_nb[UA];
+#pragma unroll
+  for (int j = 0; j < UA; ++j) {
+    const int row = (tid + 256 * j) >> 2;
+    int m = m0 + row;
+    m = m < M ? m : M - 1;
+    if (TCONV) {
+      const int qx = m % W, t = m / W;
+      a_bx[j] = qx;
+      a_by[j] = t % H;
+      a_nb[j] = (uint32_t)(t / H) * (uint32_t)(H * W);
+    } else {
+      const int ox = m % p.w_out, t = m / p.w_out;
+      a_bx[j] = ox * p.stride - p.pad;
+      a_by[j] = (t % p.h_out) * p.stride - p.pad;
+      a_nb[j] = (uint32_t)(t / p.h_out) * (uint32_t)(H * W);
+    }
+  }
+
+  float4 ra[UA][2], rb[UB][2];
+
+  auto tap_of = [&](int kk, int &ty, int &tx, int &ci) {
+    const int tap = (int)(((uint64_t)(uint32_t)kk * a.cin_magic) >> 32);
+    ci = kk - tap * Cin;
+    ty = (int)(((uint32_t)tap * inv_nkx) >> 16);
+    tx = tap - ty * nkx;
+  };
+
+  auto load_tile = [&](int kt) {
+    const int kbase = kt * BK;
+    int fty = 0, ftx = 0, fci = 0;
+    if (fast) tap_of(kbase, fty, ftx, fci);
+#pragma unroll
+    for (int j = 0; j < UA; ++j) {
+      const int oct = (tid + 256 * j) & 3;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kk = kbase + oct * 8 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < K) {
+          int ty, tx, ci;
+          if (fast) {
+            ty = fty;
+            tx = ftx;
+            ci = fci + oct * 8 + q * 4;
+          } else {
+            tap_of(kk, ty, tx, ci);
+          }
+          int iy, ix;
+          bool ok = true;
+          if (TCONV) {
+            iy = a_by[j] + ((pyc + tpad - (ky0 + 2 * ty)) >> 1);
+            ix = a_bx[j] + ((pxc + tpad - (kx0 + 2 * tx)) >> 1);
+            ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          } else {
+            iy = a_by[j] + ty;
+            ix = a_bx[j] + tx;
+            iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+          }
+          if (ok) {
+            const uint32_t off = (a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)ci;
+            v = *reinterpret_cast<const float4 *>(p.x + off);
+            if (GDN) {
+              v.x = v.x * v.x;
+              v.y = v.y * v.y;
+              v.z = v.z * v.z;
+              v.w = v.w * v.w;
+            }
+          }
+        }
+        ra[j][q] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = tid + 256 * j;
+      const int row = u >> 2, oct = u & 3;
+      const int co = n0 + row;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kk = kbase + oct * 8 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < BN * 4 && kk < K && co < Cout) {
+          uint32_t off;
+          if (TCONV) {
+            int ty, tx, ci;
+            if (fast) {
+              ty = fty;
+              tx = ftx;
+              ci = fci + oct * 8 + q * 4;
+            } else {
+              tap_of(kk, ty, tx, ci);
+            }
+            off = ((uint32_t)co * (uint32_t)(ks * ks) + (uint32_t)((ky0 + 2 * ty) * ks + kx0 + 2 * tx)) * (uint32_t)Cin +
+                  (uint32_t)ci;
+          } else {
+            off = (uint32_t)co * (uint32_t)K + (uint32_t)kk;
+          }
+          v = *reinterpret_cast<const float4 *>(p.w + off);
+        }
+        rb[j][q] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < UA; ++j) {
+      const int u = tid + 256 * j;
+      float *dst = As + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
+      *reinterpret_cast<float4 *>(dst) = make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w);
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = tid + 256 * j;
+      if (u < BN * 4) {
+        float *dst = Bs + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(rb[j][0].x, rb[j][0].z, rb[j][1].x, rb[j][1].z);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(rb[j][0].y, rb[j][0].w, rb[j][1].y, rb[j][1].w);
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const float *a_frag = As + (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+  const float *b_frag = Bs + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + j * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = s == 0 ? af[i].x : (s == 1 ? af[i].y : (s == 2 ? af[i].z : af[i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  Epilogue ep{p.bias, p.mul, p.res, p.x, p.y, p.act1, p.act2, p.mode};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
+      size_t opix = (size_t)m;
+      if (TCONV) {
+        const int qx = m % W, t = m / W;
+        const int qy = t % H, n = t / H;
+        opix = ((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (co < Cout) ep.store(opix, co, Cout, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  MfmaArgs a;
+  a.p = p;
+  a.M = MODE == AIVC_MODE_TCONV ? p.n * p.h_in * p.w_in : p.n * p.h_out * p.w_out;
+  a.cin_magic = (uint32_t)((0x100000000ull + (uint64_t)p.c_in - 1) / (uint64_t)p.c_in);
+  dim3 grid((a.M + BM - 1) / BM, (p.c_out + BN - 1) / BN, MODE == AIVC_MODE_TCONV ? 4 : 1);
+  const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN>), grid, dim3(256), lds, s, a);
+  return check_launch("conv_mfma");
+}
+
+// tile menu: {BM x BN}: 128x128, 256x64, 64x64, 128x32
+template <int MODE>
+static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
+  const long M = MODE == AIVC_MODE_TCONV ? (long)p.n * p.h_in * p.w_in : (long)p.n * p.h_out * p.w_out;
+  const int z = MODE == AIVC_MODE_TCONV ? 4 : 1;
+  const int co = p.c_out;
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((co + bn - 1) / bn) * z; };
+  if (co > 64) {
+    if (blocks(128, 128) >= 384) return launch_cfg<MODE, 2, 2, 2, 2>(p, s);
+    return launch_cfg<MODE, 2, 2, 1, 1>(p, s);
+  }
+  if (co > 32) {
+    if (blocks(256, 64) >= 384) return launch_cfg<MODE, 4, 1, 2, 2>(p, s);
+    return launch_cfg<MODE, 2, 2, 1, 1>(p, s);
+  }
+  return launch_cfg<MODE, 4, 1, 1, 1>(p, s);
+}
+
+bool conv2d_mfma_supported(const aivc_conv_params &p) {
+  if (p.c_out < 16) return false;  // thin output layers stay on the scalar kernel
+  // 32-bit element offsets inside the kernel
+  const uint64_t in_elems = (uint64_t)p.n * p.h_in * p.w_in * p.c_in;
+  const uint64_t w_elems = (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in;
+  if (in_elems >= 0xFFFFFFFFull || w_elems >= 0xFFFFFFFFull) return false;
+  if ((uint64_t)p.ksize * p.ksize * p.c_in >= 65536ull) return false;
+  return true;
+}
+
+int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
+  if (!conv2d_mfma_supported(p) && p.c_out >= 16) return AIVC_ERR_UNSUPPORTED;
+  switch (p.mode) {
+    case AIVC_MODE_CONV: return launch_mode<AIVC_MODE_CONV>(p, s);
+    case AIVC_MODE_TCONV: return launch_mode<AIVC_MODE_TCONV>(p, s);
+    case AIVC_MODE_GDN:
+    case AIVC_MODE_IGDN: return launch_mode<AIVC_MODE_GDN>(p, s);
+    default: return AIVC_ERR_UNSUPPORTED;
+  }
+}
+
 }  // namespace aivc

@@ -111,8 +111,19 @@ def gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
 
 def gdn(x, beta_eff, gamma_eff, inverse=False, res=None, algo=abi.ALGO_AUTO):
     c = x.shape[-1]
-    return conv2d(x, gamma_eff.reshape(c, 1, 1, c), beta_eff,
-                  mode=abi.MODE_IGDN if inverse else abi.MODE_GDN, res=res, algo=algo)
+    mode = abi.MODE_IGDN if inverse else abi.MODE_GDN
+    if c % 4 == 0:
+        return conv2d(x, gamma_eff.reshape(c, 1, 1, c), beta_eff, mode=mode, res=res, algo=algo)
+    # channel counts that are not a multiple of 4 (never the case in a real model): run on a zero
+    # padded copy (extra channels: x = 0, gamma = 0, beta = 1) and drop the padding
+    c4 = (c + 3) // 4 * 4
+    g = torch.zeros((c4, c4), dtype=torch.float32, device=x.device)
+    g[:c, :c] = gamma_eff
+    b = torch.ones(c4, dtype=torch.float32, device=x.device)
+    b[:c] = beta_eff
+    y = conv2d(pad_channels(x, c4), g.reshape(c4, 1, 1, c4), b, mode=mode,
+               res=None if res is None else pad_channels(res, c4), algo=algo)
+    return y[..., :c].contiguous()
 
 
 def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):

@@ -37,11 +37,24 @@ CONV_CASES = [
     (abi.MODE_IGDN, 1, 1, 0, 16, 16, 5, 7, 0, 0, False, True),
     (abi.MODE_CONV, 5, 2, 2, 64, 128, 33, 47, 0, 0, False, False),
     (abi.MODE_CONV, 3, 1, 1, 128, 128, 19, 21, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_CONV, 3, 2, 1, 128, 128, 40, 44, abi.ACT_LEAKY, 0, False, False),
+    (abi.MODE_CONV, 5, 2, 2, 12, 64, 47, 61, 0, 0, False, False),
+    (abi.MODE_CONV, 5, 2, 2, 128, 64, 30, 34, 0, 0, False, False),
+    (abi.MODE_CONV, 1, 1, 0, 128, 64, 23, 29, abi.ACT_LEAKY, 0, False, False),
+    (abi.MODE_CONV, 1, 2, 0, 128, 128, 31, 29, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 128, 128, 17, 19, 0, 0, False, False),
+    (abi.MODE_TCONV, 3, 2, 0, 128, 128, 17, 19, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_TCONV, 5, 2, 0, 128, 64, 33, 35, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 32, 128, 9, 11, abi.ACT_LEAKY, 0, False, False),
+    (abi.MODE_GDN, 1, 1, 0, 128, 128, 33, 31, 0, 0, False, False),
+    (abi.MODE_IGDN, 1, 1, 0, 64, 64, 33, 31, 0, 0, False, True),
+    (abi.MODE_CONV, 3, 1, 1, 128, 192, 9, 11, 0, 0, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 64, 256, 20, 20, 0, 0, False, False),
 ]
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('algo', [abi.ALGO_DIRECT, abi.ALGO_AUTO])
+@pytest.mark.parametrize('algo', [abi.ALGO_DIRECT, abi.ALGO_AUTO, abi.ALGO_MFMA])
 def test_conv_family_bit_exact(case, algo, oracle, cuda):
     from aivc_amd import ops
     mode, k, s, pad, ci, co, h, w, a1, a2, use_mul, use_res = case

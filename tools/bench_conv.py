@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-layer throughput of aivc_conv2d on the shapes of the 1080p workload (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from aivc_amd import abi, ops
+
+SHAPES = [  # name, mode, k, s, pad, cin, cout, h_in, w_in
+    ('ga0 conv5s2 12->64 @1080p', abi.MODE_CONV, 5, 2, 2, 12, 64, 1080, 1920),
+    ('gdn64 @540p', abi.MODE_GDN, 1, 1, 0, 64, 64, 540, 960),
+    ('ga1 conv5s2 64->128 @540p', abi.MODE_CONV, 5, 2, 2, 64, 128, 540, 960),
+    ('gdn128 @270p', abi.MODE_GDN, 1, 1, 0, 128, 128, 270, 480),
+    ('cheng conv3s2 128 @270p', abi.MODE_CONV, 3, 2, 1, 128, 128, 270, 480),
+    ('cheng conv3 128 @135p', abi.MODE_CONV, 3, 1, 1, 128, 128, 135, 240),
+    ('att 1x1 128->64 @135p', abi.MODE_CONV, 1, 1, 0, 128, 64, 135, 240),
+    ('att 3x3 64->64 @135p', abi.MODE_CONV, 3, 1, 1, 64, 64, 135, 240),
+    ('ga4 conv5s2 128->64 @135p', abi.MODE_CONV, 5, 2, 2, 128, 64, 135, 240),
+    ('res 3x3 128 @68p', abi.MODE_CONV, 3, 1, 1, 128, 128, 68, 120),
+    ('gs1 tconv5 128->128 @68p', abi.MODE_TCONV, 5, 2, 0, 128, 128, 68, 120),
+    ('gs2 tconv3 128->128 @135p', abi.MODE_TCONV, 3, 2, 0, 128, 128, 135, 240),
+    ('gs3 tconv5 128->64 @270p', abi.MODE_TCONV, 5, 2, 0, 128, 64, 270, 480),
+    ('gs4 tconv5 64->3 @540p', abi.MODE_TCONV, 5, 2, 0, 64, 3, 540, 960),
+    ('gs4 tconv5 64->6 @540p', abi.MODE_TCONV, 5, 2, 0, 64, 6, 540, 960),
+]
+
+
+def main():
+    dev = torch.device('cuda:0')
+    tot_f, tot_t = 0.0, 0.0
+    for name, mode, k, s, pad, ci, co, h, w in SHAPES:
+        x = torch.randn(1, h, w, ci, device=dev)
+        wt = torch.randn(co, k, k, ci, device=dev) * 0.05
+        b = torch.rand(co, device=dev) + 0.5
+        if mode in (abi.MODE_GDN, abi.MODE_IGDN):
+            wt = wt.abs()
+        ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+        taps = k * k if mode != abi.MODE_TCONV else k * k / 4.0
+        flops = 2.0 * taps * ci * co * ho * wo
+        for algo in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_DIRECT, abi.ALGO_MFMA]):
+            for _ in range(2):
+                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 5
+            e0.record()
+            for _ in range(n):
+                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            print('%-32s algo=%d  %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, ms, flops / 1e9, flops / ms / 1e9))
+        tot_f += flops
+        tot_t += ms
+    print('sum: %.1f GFLOP in %.2f ms -> %.1f TFLOP/s' % (tot_f / 1e9, tot_t, tot_f / tot_t / 1e9))
+
+
+if __name__ == '__main__':
+    main()
