@@ -21,7 +21,7 @@ LP = 514
 CDF_ROW = 520
 BALLE_PARAMS = 43
 MAX_MAPS = 256
-RC_MAX_STREAMS = 8
+RC_MAX_STREAMS = 64
 
 FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 
@@ -96,6 +96,11 @@ def declare(lib, suffix=''):
         fn.argtypes = list(args) + [C.c_void_p]
         fn.restype = C.c_int
         fns[name] = fn
+    if not suffix:
+        var = lib.aivc_conv2d_variant
+        var.argtypes = [_P(ConvParams)]
+        var.restype = C.c_int
+        fns['aivc_conv2d_variant'] = var
     ver = getattr(lib, 'aivc_abi_version' + suffix)
     ver.argtypes = []
     ver.restype = C.c_int

@@ -10,117 +10,181 @@ import math
 import torch
 
 from . import ops
-from .func_util.GOP_structure import FRAME_B, FRAME_I, FRAME_P, generate_gop_struct
+from .func_util.GOP_structure import FRAME_B, FRAME_I, FRAME_P, coding_levels, generate_gop_struct
 from .real_life import cat_binary_files as container
 from .real_life import header as hdr
-from .real_life.bitstream import finalize_frame, split_sections
+from .real_life.bitstream import finalize_frames, split_sections
 
 
 def frame_index(name):
     return int(name.split('_')[-1])
 
 
+def _stack(planes_list):
+    return {k: torch.cat([p[k] for p in planes_list], dim=0) for k in 'yuv'}
+
+
+def _unstack(planes, n):
+    return [{k: planes[k][i:i + 1] for k in 'yuv'} for i in range(n)]
+
+
 class FrameCodec:
-    def __init__(self, full_net):
+    """max_batch bounds how many frames of one dependency level are pushed through the transforms
+    together (activations of a 1080p frame at 1/2 resolution are 133 MB per 64-channel tensor)."""
+
+    def __init__(self, full_net, max_batch=8):
         self.net = full_net
         self.mof = full_net.mode_net.mode_net
         self.cod = full_net.codec_net.codec_net
+        self.max_batch = max_batch
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def to444(planes, h, w, device):
-        if planes is None:
-            return torch.zeros((1, h, w, 3), dtype=torch.float32, device=device)
+    def to444(planes):
         return ops.yuv420_to_444(planes['y'], planes['u'], planes['v'], c_store=3)
 
-    def _motion(self, mof_out, prev444, next444, h, w, frame_type, want_aux):
-        return ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3, want_aux=want_aux)
-
-    def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
-        """-> {'bytes', 'rec' (uint8 planes), 'data_dim', + aux tensors when want_aux}"""
-        dev = cur['y'].device
-        h, w = cur['y'].shape[-2:]
-        code = self.to444(cur, h, w, dev)
-        sections = [None] * 4
+    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
+        """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts
+        (prev/nxt ignored where the frame type has no such reference).
+        -> list of {'bytes', 'rec', 'data_dim'[, 'aux']}"""
+        n = len(cur)
+        h, w = cur[0]['y'].shape[-2:]
+        code = self.to444(_stack(cur))
+        sections = [[None] * 4 for _ in range(n)]
         pred = skip = None
         aux = {}
         if frame_type != FRAME_I:
-            prev444 = self.to444(prev, h, w, dev)
-            next444 = self.to444(nxt if frame_type == FRAME_B else None, h, w, dev)
+            prev444 = self.to444(_stack(prev))
+            next444 = self.to444(_stack(nxt)) if frame_type == FRAME_B else torch.zeros_like(prev444)
             a = self.mof.analyse(torch.cat((code, prev444, next444), dim=3), frame_type, idx_rate)
             short_in = torch.cat((prev444, next444), dim=3) if frame_type == FRAME_B else None
             mof_out = self.mof.synthesise(a['y_hat'], short_in)
-            wb = self._motion(mof_out, prev444, next444, h, w, frame_type, want_aux)
+            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3, want_aux=want_aux)
             pred, skip = wb['pred'], wb['skip']
-            sections[0] = self.mof.ac.pend_z(a['q_z'])
-            sections[1] = self.mof.ac.pend_y(a['q_y'], a['sigma'])
+            for i, (sz, sy) in enumerate(zip(self.mof.ac.pend_z(a['q_z']), self.mof.ac.pend_y(a['q_y'], a['sigma']))):
+                sections[i][0], sections[i][1] = sz, sy
             if want_aux:
                 aux.update(alpha=wb['alpha'], beta=wb['beta'], warping=wb['x_warp'])
         zero_pred = torch.zeros_like(code) if pred is None else pred
         c = self.cod.analyse(torch.cat((code, zero_pred), dim=3), frame_type, idx_rate)
         cod_out = self.cod.synthesise(c['y_hat'], pred)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
-        sections[2] = self.cod.ac.pend_z(c['q_z'])
-        sections[3] = self.cod.ac.pend_y(c['q_y'], c['sigma'])
+        for i, (sz, sy) in enumerate(zip(self.cod.ac.pend_z(c['q_z']), self.cod.ac.pend_y(c['q_y'], c['sigma']))):
+            sections[i][2], sections[i][3] = sz, sy
         data_dim = {'x': (h, w), 'y': c['dim_y'], 'z': c['dim_z'],
                     'x_uv': (math.ceil(h / 2), math.ceil(w / 2))}
-        out = {'bytes': finalize_frame(sections), 'rec': dict(zip('yuv', rec8)), 'data_dim': data_dim}
+        recs = _unstack(dict(zip('yuv', rec8)), n)
         if want_aux:
             aux['code'] = code
-            out['aux'] = aux
-        return out
+        return {'sections': sections, 'rec': recs, 'data_dim': data_dim, 'aux': aux}
 
-    def _decode_net(self, net, payload_z, payload_y, frame_type, data_dim, in_shortcut, idx_rate, device):
+    def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
+        out = self.encode_batch([cur], [prev], [nxt], frame_type, idx_rate, want_aux)
+        res = {'bytes': finalize_frames(out['sections'])[0], 'rec': out['rec'][0], 'data_dim': out['data_dim']}
+        if want_aux:
+            res['aux'] = out['aux']
+        return res
+
+    def _decode_net(self, net, pay_z, pay_y, frame_type, data_dim, in_shortcut, idx_rate, device):
         h_y, w_y = data_dim['y']
         h_z, w_z = data_dim['z']
-        q_z = net.ac.decode_z(payload_z, 1, h_z, w_z, net.nb_ft_z, device)
-        y_hat = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(payload_y, sigma), frame_type,
+        q_z = net.ac.decode_z(pay_z, h_z, w_z, net.nb_ft_z, device)
+        y_hat = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(pay_y, sigma), frame_type,
                                          (h_y, w_y), idx_rate)
         return net.synthesise(y_hat, in_shortcut)
 
-    def decode_frame(self, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
-        """Mirror of Decoder.decode (src/real_life/decode.py:455-580) -> uint8 planes dict."""
+    def decode_batch(self, frames_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
+        """Mirror of Decoder.decode (src/real_life/decode.py:455-580) for n frames of one type.
+        -> list of uint8 plane dicts."""
         device = device or torch.device('cuda')
+        n = len(frames_bytes)
         h, w = data_dim['x']
-        sec = split_sections(frame_bytes)
+        secs = [split_sections(b) for b in frames_bytes]
         pred = skip = None
         if frame_type != FRAME_I:
-            prev444 = self.to444(prev, h, w, device)
-            next444 = self.to444(nxt if frame_type == FRAME_B else None, h, w, device)
+            prev444 = self.to444(_stack(prev))
+            next444 = self.to444(_stack(nxt)) if frame_type == FRAME_B else torch.zeros_like(prev444)
             short_in = torch.cat((prev444, next444), dim=3) if frame_type == FRAME_B else None
-            mof_out = self._decode_net(self.mof, sec[0], sec[1], frame_type, data_dim, short_in, idx_rate, device)
-            wb = self._motion(mof_out, prev444, next444, h, w, frame_type, False)
+            mof_out = self._decode_net(self.mof, [s[0] for s in secs], [s[1] for s in secs], frame_type, data_dim,
+                                       short_in, idx_rate, device)
+            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3)
             pred, skip = wb['pred'], wb['skip']
-        cod_out = self._decode_net(self.cod, sec[2], sec[3], frame_type, data_dim, pred, idx_rate, device)
+        cod_out = self._decode_net(self.cod, [s[2] for s in secs], [s[3] for s in secs], frame_type, data_dim, pred,
+                                   idx_rate, device)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
-        return dict(zip('yuv', rec8))
+        return _unstack(dict(zip('yuv', rec8)), n)
+
+    def decode_frame(self, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
+        return self.decode_batch([frame_bytes], [prev], [nxt], frame_type, data_dim, idx_rate, device)[0]
 
     # ------------------------------------------------------------------------------------------
-    def encode_gop(self, frames, gop_name, idx_rate=0.):
-        """frames: list (display order) of uint8 plane dicts, len == len(GOP struct).
-        -> (gop bytes, reconstructions in display order, data_dim)"""
+    # Level-synchronous scheduling: frames of one dependency level (of ALL units handed in) only
+    # depend on earlier levels, so they are pushed through the networks as one batch and their
+    # entropy streams are coded concurrently.  Frames are stored in display order in the container,
+    # so this yields the same bytes as the reference's depth-first order (SURVEY.md 3.5).
+    def _chunks(self, gop, level, unit_ids):
+        """(frame type, [(unit, frame name), ...]) batches of at most max_batch same-type frames of one
+        dependency level (a level of a chained GOP mixes P and B frames)."""
+        for ftype in sorted({gop[f]['type'] for f in level}):
+            items = [(u, f) for u in unit_ids for f in level if gop[f]['type'] == ftype]
+            for s in range(0, len(items), self.max_batch):
+                yield ftype, items[s:s + self.max_batch]
+
+    def encode_units(self, units, gop_name, idx_rate=0.):
+        """units: list of frame lists (display order, each len == len(GOP struct)).
+        -> ([gop bytes per unit], [reconstructions per unit], data_dim)"""
         gop = generate_gop_struct(gop_name)
-        order = sorted(gop, key=lambda f: gop[f]['coding_order'])
-        rec, fbytes, data_dim = {}, {}, None
-        for f in order:
-            d = gop[f]
-            out = self.encode_frame(frames[frame_index(f)], rec.get(d['prev_ref']), rec.get(d['next_ref']),
-                                    d['type'], idx_rate)
-            rec[f], fbytes[f], data_dim = out['rec'], out['bytes'], out['data_dim']
         names = sorted(gop, key=frame_index)
-        blob = container.pack_gop(hdr.gop_header_bytes(gop_name, idx_rate), [fbytes[f] for f in names])
-        return blob, [rec[f] for f in names], data_dim
+        rec = [dict() for _ in units]
+        fbytes = [dict() for _ in units]
+        data_dim = None
+        for level in coding_levels(gop):
+            pending = []
+            for ftype, chunk in self._chunks(gop, level, range(len(units))):
+                out = self.encode_batch([units[u][frame_index(f)] for u, f in chunk],
+                                        [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
+                                        [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate)
+                data_dim = out['data_dim']
+                for (u, f), r in zip(chunk, out['rec']):
+                    rec[u][f] = r
+                pending.append((chunk, out['sections']))
+            # entropy-code the whole level in one go (one sync, one batched launch)
+            all_secs = [s for _, secs in pending for s in secs]
+            for (u, f), b in zip([it for chunk, _ in pending for it in chunk], finalize_frames(all_secs)):
+                fbytes[u][f] = b
+        head = hdr.gop_header_bytes(gop_name, idx_rate)
+        blobs = [container.pack_gop(head, [fbytes[u][f] for f in names]) for u in range(len(units))]
+        return blobs, [[rec[u][f] for f in names] for u in range(len(units))], data_dim
+
+    def decode_units(self, gop_blobs, data_dim, device=None):
+        """-> [reconstructions (display order) per unit]"""
+        parsed = [container.unpack_gop(g) for g in gop_blobs]
+        out = [None] * len(gop_blobs)
+        groups = {}
+        for i, (name, idx_rate, _) in enumerate(parsed):
+            groups.setdefault((name, idx_rate), []).append(i)
+        for (gop_name, idx_rate), members in groups.items():
+            gop = generate_gop_struct(gop_name)
+            names = sorted(gop, key=frame_index)
+            rec = {i: {} for i in members}
+            for level in coding_levels(gop):
+                for ftype, chunk in self._chunks(gop, level, members):
+                    dec = self.decode_batch([parsed[i][2][frame_index(f)] for i, f in chunk],
+                                            [rec[i].get(gop[f]['prev_ref']) for i, f in chunk],
+                                            [rec[i].get(gop[f]['next_ref']) for i, f in chunk], ftype, data_dim,
+                                            idx_rate, device)
+                    for (i, f), r in zip(chunk, dec):
+                        rec[i][f] = r
+            for i in members:
+                out[i] = [rec[i][f] for f in names]
+        return out
+
+    def encode_gop(self, frames, gop_name, idx_rate=0.):
+        blobs, recs, data_dim = self.encode_units([frames], gop_name, idx_rate)
+        return blobs[0], recs[0], data_dim
 
     def decode_gop(self, gop_bytes, data_dim, device=None):
-        gop_name, idx_rate, fbytes = container.unpack_gop(gop_bytes)
-        gop = generate_gop_struct(gop_name)
-        order = sorted(gop, key=lambda f: gop[f]['coding_order'])
-        rec = {}
-        for f in order:
-            d = gop[f]
-            rec[f] = self.decode_frame(fbytes[frame_index(f)], rec.get(d['prev_ref']), rec.get(d['next_ref']),
-                                       d['type'], data_dim, idx_rate, device)
-        return [rec[f] for f in sorted(gop, key=frame_index)]
+        return self.decode_units([gop_bytes], data_dim, device)[0]
 
     # ------------------------------------------------------------------------------------------
     def encode_video(self, frames, gop_name, idx_starting_frame=0, idx_end_frame=None, idx_rate=0.,
@@ -133,16 +197,13 @@ class FrameCodec:
         idx_end_frame = idx_starting_frame + n - 1 if idx_end_frame is None else idx_end_frame
         unit = len(generate_gop_struct(gop_name))
         nb_gop = math.ceil(n / unit)
-        gops, recs, data_dim = [], [], None
-        for u in range(nb_gop):
-            if unit_filter is not None and not unit_filter(u):
-                gops.append(None)
-                recs.append(None)
-                continue
-            chunk = [frames[min(u * unit + i, n - 1)] for i in range(unit)]
-            blob, rec, data_dim = self.encode_gop(chunk, gop_name, idx_rate)
-            gops.append(blob)
-            recs.append(rec)
+        mine = [u for u in range(nb_gop) if unit_filter is None or unit_filter(u)]
+        gops, recs, data_dim = [None] * nb_gop, [None] * nb_gop, None
+        if mine:
+            units = [[frames[min(u * unit + i, n - 1)] for i in range(unit)] for u in mine]
+            blobs, rr, data_dim = self.encode_units(units, gop_name, idx_rate)
+            for u, b, r in zip(mine, blobs, rr):
+                gops[u], recs[u] = b, r
         return {'gops': gops, 'recs': recs, 'data_dim': data_dim, 'nb_gop': nb_gop,
                 'idx_starting_frame': idx_starting_frame, 'idx_end_frame': idx_end_frame}
 
@@ -153,13 +214,15 @@ class FrameCodec:
         return container.pack_video(vh, enc['gops'])
 
     def decode_video(self, blob, device=None, unit_filter=None):
-        """-> list of uint8 plane dicts for frames idx_first..idx_last (padded frames removed)."""
+        """-> list of uint8 plane dicts for frames idx_first..idx_last (padded frames removed);
+        frames of units filtered out are None."""
         data_dim, first, last, gops = container.unpack_video(blob)
+        mine = [u for u in range(len(gops)) if unit_filter is None or unit_filter(u)]
+        dec = dict(zip(mine, self.decode_units([gops[u] for u in mine], data_dim, device))) if mine else {}
         frames = []
         for u, g in enumerate(gops):
-            if unit_filter is not None and not unit_filter(u):
-                name, _, fb = container.unpack_gop(g)
-                frames.extend([None] * len(fb))
-                continue
-            frames.extend(self.decode_gop(g, data_dim, device))
+            if u in dec:
+                frames.extend(dec[u])
+            else:
+                frames.extend([None] * len(container.unpack_gop(g)[2]))
         return frames[:last - first + 1], data_dim, first, last

@@ -48,6 +48,14 @@ static int validate_conv(const aivc_conv_params *p) {
   return AIVC_OK;
 }
 
+AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
+  int rc = validate_conv(p);
+  if (rc != AIVC_OK) return rc;
+  if (p->algo == AIVC_ALGO_DIRECT) return 0;
+  if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
+  return 0;
+}
+
 AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;

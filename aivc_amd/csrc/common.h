@@ -50,5 +50,6 @@ struct Epilogue {
 int conv2d_direct(const aivc_conv_params &p, hipStream_t s);
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s);  // AIVC_ERR_UNSUPPORTED if shape not covered
 bool conv2d_mfma_supported(const aivc_conv_params &p);
+int conv2d_mfma_variant(const aivc_conv_params &p);  // 100 + 10*mode + tile id
 
 }  // namespace aivc

@@ -142,32 +142,32 @@ __global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__
 // ------------------------------------------------------------------ range encoder
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// MSB-first bit packer.  All state is wave-uniform; every lane issues the same store (one
+// transaction), which keeps the hot loop free of exec-mask branches.  The word under construction
+// is re-stored on every call and simply overwritten until it is complete.
 struct BitSink {
   uint32_t *out;       // 4-byte aligned
-  uint32_t cap_words;  // capacity in 32-bit words
+  uint32_t cap_words;  // capacity in 32-bit words (>= 1)
   uint32_t n_words;
   uint64_t acc;
-  int nbits;  // < 32 between calls
-  bool overflow;
-  __device__ __forceinline__ void put(uint32_t bits, int nb, int lane) {  // nb in [1, 32]
+  uint32_t nbits;  // < 32 between calls
+  uint32_t overflow;
+  __device__ __forceinline__ void put(uint32_t bits, uint32_t nb) {  // nb in [0, 32]
     acc = (acc << nb) | (uint64_t)bits;
     nbits += nb;
-    if (nbits >= 32) {
-      const uint32_t word = (uint32_t)(acc >> (nbits - 32));
-      if (n_words < cap_words) {
-        if (lane == 0) out[n_words] = __builtin_bswap32(word);
-      } else {
-        overflow = true;
-      }
-      n_words++;
-      nbits -= 32;
-    }
+    const bool full = nbits >= 32;
+    const uint32_t w = full ? (uint32_t)(acc >> (nbits - 32)) : (uint32_t)(acc << (32 - nbits));
+    const uint32_t idx = n_words < cap_words ? n_words : cap_words - 1;
+    overflow |= (uint32_t)(n_words >= cap_words);
+    out[idx] = __builtin_bswap32(w);
+    n_words += full ? 1u : 0u;
+    nbits -= full ? 32u : 0u;
   }
-  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count, int lane) {
+  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count) {
     while (count > 0) {
-      const int r = count > 32 ? 32 : (int)count;
+      const uint32_t r = count > 32 ? 32 : count;
       const uint32_t ones = r == 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
-      put(bit ? ones : 0u, r, lane);
+      put(bit ? ones : 0u, r);
       count -= r;
     }
   }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
-  BitSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, false};
+  BitSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, 0};
   uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
   const uint32_t *src = bounds + st.in_off;
   for (uint32_t base = 0; base < st.n_sym; base += 64) {
@@ -189,57 +189,48 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
       const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
       high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
       low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
-      // E1 / E2: the n leading bits on which low and high agree are final
-      const int n = __builtin_clz(low ^ high);  // low < high always: 0 <= n <= 31
-      if (n > 0) {
+      // E1 / E2: the n leading bits on which low and high agree are final (low < high: n <= 31)
+      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
+      const uint32_t top = (uint32_t)(((uint64_t)low << n) >> 32);  // the n leading bits of low
+      if (pending == 0) {
+        sink.put(top, n);
+      } else if (n > 0) {
         const uint32_t b0 = low >> 31;
-        sink.put(b0, 1, lane);
-        sink.put_run(b0 ^ 1u, pending, lane);
+        sink.put(b0, 1);
+        sink.put_run(b0 ^ 1u, pending);
         pending = 0;
-        if (n > 1) sink.put((low << 1) >> (33 - n), n - 1, lane);
-        low <<= n;
-        high = (high << n) | ((1u << n) - 1u);
+        sink.put(top & ((1u << (n - 1)) - 1u), n - 1);
       }
+      low <<= n;
+      high = (high << n) | ((1u << n) - 1u);
       // E3: now low = 0..., high = 1...; every further position with (low,high) = (1,0) straddles
       const uint32_t y = (low & ~high) << 1;
-      const int m = __builtin_clz(~y);  // leading ones of y (0..31)
-      if (m > 0) {
-        pending += (uint32_t)m;
-        low = (low << m) & 0x7FFFFFFFu;
-        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-      }
+      const uint32_t m = (uint32_t)__builtin_clz(~y);  // leading ones of y (0..31)
+      pending += m;
+      low = (low << m) & 0x7FFFFFFFu;
+      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
     }
   }
   pending += 1;
   const uint32_t fb = low < 0x40000000u ? 0u : 1u;
-  sink.put(fb, 1, lane);
-  sink.put_run(fb ^ 1u, pending, lane);
-  // flush the last partial word byte by byte (zero padded to a byte boundary)
-  uint32_t total = sink.n_words * 4u;
-  if (sink.nbits > 0) {
-    const int nbytes = (sink.nbits + 7) / 8;
-    const uint32_t word = (uint32_t)(sink.acc << (32 - sink.nbits));  // MSB aligned, zero padded
-    for (int i = 0; i < nbytes; ++i) {
-      if (total + i < st.out_cap) {
-        if (lane == 0) out[st.out_off + total + i] = (uint8_t)(word >> (24 - 8 * i));
-      } else {
-        sink.overflow = true;
-      }
-    }
-    total += nbytes;
-  }
+  sink.put(fb, 1);
+  sink.put_run(fb ^ 1u, pending);
+  sink.put(0u, 0u);  // store the bits left over after the last completed word (MSB aligned, zero padded)
+  // count the bytes of the partial last word
+  const uint32_t total = sink.n_words * 4u + (sink.nbits + 7u) / 8u;
+  if (total > st.out_cap) sink.overflow = 1;
   if (lane == 0) out_len[blockIdx.x] = sink.overflow ? 0xFFFFFFFFu : total;
 }
 
 // ------------------------------------------------------------------ range decoder
 struct BitSrc {
-  const uint32_t *in;  // 4-byte aligned, zero padded
+  const uint32_t *in;  // 4-byte aligned
   uint32_t n_words;    // words that may be read (beyond: zeros)
   uint32_t tail_bytes; // payload bytes in the last word (0 = all four)
   uint32_t wi;         // next word index
   uint32_t chunk;      // per-lane: word (wi & ~63) + lane
   uint64_t win;        // upcoming bits, MSB aligned
-  int avail;
+  uint32_t avail;
   int lane;
   __device__ __forceinline__ void load_chunk() {
     const uint32_t idx = (wi & ~63u) + (uint32_t)lane;
@@ -261,9 +252,8 @@ struct BitSrc {
     win |= (uint64_t)next_word();
     avail = 64;
   }
-  __device__ __forceinline__ uint32_t take(int n) {  // n in [0, 32]
-    if (n == 0) return 0u;
-    const uint32_t v = (uint32_t)(win >> (64 - n));
+  __device__ __forceinline__ uint32_t take(uint32_t n) {  // n in [0, 32]
+    const uint32_t v = (uint32_t)((win >> 32) >> (32 - n));  // n = 0 -> shift by 32 of a 32-bit value in u64: 0
     win <<= n;
     avail -= n;
     if (avail <= 32) {
@@ -281,9 +271,11 @@ struct RowRegs {
   uint32_t nx;  // entry 8*lane+8
 };
 
-__device__ __forceinline__ uint32_t sel16(const uint4 &e, int idx) {  // idx in [0, 7]
-  const uint32_t d = idx < 2 ? e.x : (idx < 4 ? e.y : (idx < 6 ? e.z : e.w));
-  return (idx & 1) ? (d >> 16) : (d & 0xFFFFu);
+// #lanes whose CDF entry e satisfies e <= count, without computing count:
+//   e <= floor(num / span)  <=>  e * span <= num  <=>  e * (span - 1) + e <= num
+__device__ __forceinline__ uint32_t le_count(uint32_t e, uint32_t hl, uint64_t num) {
+  const uint64_t prod = (uint64_t)e * (uint64_t)hl + (uint64_t)e;
+  return (uint32_t)__builtin_popcountll(__ballot(prod <= num));
 }
 
 __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
@@ -334,36 +326,30 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
       const uint32_t i = base + g;
       if (i < st.n_sym) {
         const uint4 e = cur[g].e;
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        const uint32_t hl = high - low;  // span - 1
         const uint64_t num = ((((uint64_t)value - (uint64_t)low) + 1) << 16) - 1;
-        // exact: the quotient is < 2^16 and the denominator < 2^33, so the correctly rounded
-        // fp64 quotient can never cross an integer boundary
-        const uint32_t count = (uint32_t)((double)num / (double)span);
-        int cnt = 0;
-        cnt += (e.x & 0xFFFFu) <= count;
-        cnt += (e.x >> 16) <= count;
-        cnt += (e.y & 0xFFFFu) <= count;
-        cnt += (e.y >> 16) <= count;
-        cnt += (e.z & 0xFFFFu) <= count;
-        cnt += (e.z >> 16) <= count;
-        cnt += (e.w & 0xFFFFu) <= count;
-        cnt += (e.w >> 16) <= count;
-        const unsigned long long mask = __ballot((e.x & 0xFFFFu) <= count);
-        int L = __builtin_popcountll(mask) - 1;
-        L = L < 0 ? 0 : L;
-        const int idx = cnt > 0 ? cnt - 1 : 0;
-        const uint32_t lo_l = sel16(e, idx);
-        const uint32_t hi_l = idx == 7 ? cur[g].nx : sel16(e, idx + 1);
-        const uint32_t packed = lo_l | (hi_l << 16) | 0u;
-        const uint32_t pk = rl(packed, L);
-        const int idxL = (int)rl((uint32_t)idx, L);
-        uint32_t m = (uint32_t)(8 * L + idxL);
-        uint32_t pk2 = pk;
-        {  // symbol 512 (never produced by our encoder) keeps torchac's semantics on foreign streams
-          const uint32_t e512 = rl(cur[g].nx, 63);
-          if (m == 511u && e512 <= count) {
+        // entries are strictly increasing over the row: #(entries <= count) = symbol + 1
+        uint32_t total = le_count(e.x & 0xFFFFu, hl, num) + le_count(e.x >> 16, hl, num) +
+                         le_count(e.y & 0xFFFFu, hl, num) + le_count(e.y >> 16, hl, num) +
+                         le_count(e.z & 0xFFFFu, hl, num) + le_count(e.z >> 16, hl, num) +
+                         le_count(e.w & 0xFFFFu, hl, num) + le_count(e.w >> 16, hl, num);
+        uint32_t m = total > 0 ? total - 1 : 0;
+        const int L = (int)(m >> 3);
+        const uint32_t idx = m & 7u;
+        // entries 8L .. 8L+8 of the row as scalars
+        const uint64_t lo64 = (uint64_t)rl(e.x, L) | ((uint64_t)rl(e.y, L) << 32);
+        const uint64_t hi64 = (uint64_t)rl(e.z, L) | ((uint64_t)rl(e.w, L) << 32);
+        const uint32_t nxL = rl(cur[g].nx, L);
+        const uint32_t pos = idx * 16u;
+        uint32_t c_lo = (uint32_t)((pos < 64 ? lo64 >> pos : hi64 >> (pos - 64)) & 0xFFFFu);
+        const uint32_t pos1 = pos + 16u;
+        uint32_t c_hi = idx == 7 ? nxL : (uint32_t)((pos1 < 64 ? lo64 >> pos1 : hi64 >> (pos1 - 64)) & 0xFFFFu);
+        if (m == 511u) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign streams
+          const uint64_t p512 = (uint64_t)nxL * (uint64_t)hl + (uint64_t)nxL;
+          if (p512 <= num) {
             m = 512u;
-            pk2 = e512;  // c_hi = 0x10000 handled below
+            c_lo = nxL;
+            c_hi = 0x10000u;
           }
         }
         if (lane == (int)(i & 63u)) mysym = m;
@@ -372,17 +358,15 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
           if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
         }
         if (i != st.n_sym - 1) {
-          const uint32_t c_lo = pk2 & 0xFFFFu, c_hi = m == 512u ? 0x10000u : (pk2 >> 16);
+          const uint64_t span = (uint64_t)hl + 1;
           high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
           low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
-          const int n = __builtin_clz(low ^ high);
-          if (n > 0) {
-            low <<= n;
-            high = (high << n) | ((1u << n) - 1u);
-            value = (value << n) | src.take(n);
-          }
+          const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
+          low <<= n;
+          high = (high << n) | ((1u << n) - 1u);
+          value = (uint32_t)(((uint64_t)value << n)) | src.take(n);
           const uint32_t y = (low & ~high) << 1;
-          const int m3 = __builtin_clz(~y);
+          const uint32_t m3 = (uint32_t)__builtin_clz(~y);
           if (m3 > 0) {
             low = (low << m3) & 0x7FFFFFFFu;
             high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);

@@ -23,11 +23,11 @@ SECTION_NAMES = ('mofnet_z', 'mofnet_y', 'codecnet_z', 'codecnet_y')
 
 
 class PendingSection:
-    """A latent whose symbols are known on the device but not yet range-coded."""
+    """A latent of ONE frame whose symbols are known on the device but not yet range-coded.
+    q / sigma are [1,h,w,c] views; `flags` is that frame's row of a batched non-zero-map tensor."""
 
-    def __init__(self, mode, q, sigma=None, table=None):
-        self.mode, self.q, self.sigma, self.table = mode, q, sigma, table
-        self.flags = ops.nonzero_flags(q) if mode == 'laplace' else None  # async, no sync here
+    def __init__(self, mode, q, sigma=None, table=None, flags=None):
+        self.mode, self.q, self.sigma, self.table, self.flags = mode, q, sigma, table, flags
 
 
 def split_sections(frame_bytes):
@@ -40,38 +40,49 @@ def split_sections(frame_bytes):
     return out
 
 
-def finalize_frame(sections):
-    """sections: list of 4 PendingSection or None (None = empty section).  Runs the CDF-bound and
-    range-encode kernels (one wavefront per section, concurrently) and returns the frame bytes."""
-    heads, jobs = [None] * 4, []
-    for i, s in enumerate(sections):
-        if s is None:
-            continue
-        if s.mode == 'laplace':
-            flags = s.flags.cpu().numpy()  # the only host sync of the entropy stage: C bytes
-            maps = [int(c) for c in np.nonzero(flags)[0]]
-            heads[i] = bytes([len(maps)]) + bytes(maps)
-            if maps:
-                jobs.append((i, ops.laplace_bounds(s.sigma, s.q, maps)))
-        else:
-            heads[i] = b''
-            jobs.append((i, ops.table_bounds(s.table, s.q)))
-    payload = [b''] * 4
+def finalize_frames(frames_sections):
+    """frames_sections: list (one entry per frame) of 4-lists of PendingSection / None.
+    One host sync for all non-zero-map flags, then the CDF-bound kernels and ONE batched
+    range-encode launch per 64 streams (a wavefront per stream, all concurrent), one D2H.
+    Returns the list of frame byte strings."""
+    lap = [(fi, si, s) for fi, secs in enumerate(frames_sections) for si, s in enumerate(secs)
+           if s is not None and s.mode == 'laplace']
+    flags_h = torch.stack([s.flags for _, _, s in lap]).cpu().numpy() if lap else None  # the one sync
+    heads = [[None] * 4 for _ in frames_sections]
+    jobs = []
+    for j, (fi, si, s) in enumerate(lap):
+        maps = [int(c) for c in np.nonzero(flags_h[j])[0]]
+        heads[fi][si] = bytes([len(maps)]) + bytes(maps)
+        if maps:
+            jobs.append((fi, si, ops.laplace_bounds(s.sigma, s.q, maps)))
+    for fi, secs in enumerate(frames_sections):
+        for si, s in enumerate(secs):
+            if s is not None and s.mode == 'pmf':
+                heads[fi][si] = b''
+                jobs.append((fi, si, ops.table_bounds(s.table, s.q)))
+    payload = [[b''] * 4 for _ in frames_sections]
     if jobs:
-        out, lens, offs = ops.range_encode([b for _, b in jobs])
+        out, lens, offs = ops.range_encode([b for _, _, b in jobs])
         out_h, lens_h = out.cpu().numpy(), lens.cpu().numpy()
-        for (i, _), (off, _cap), ln in zip(jobs, offs, lens_h):
+        for (fi, si, _), (off, _cap), ln in zip(jobs, offs, lens_h):
             if int(ln) < 0:
                 raise RuntimeError('range encoder output buffer overflow')
-            payload[i] = out_h[off:off + int(ln)].tobytes()
-    frame = b''
-    for i in range(4):
-        if sections[i] is None:
-            frame += (0).to_bytes(4, 'big')
-        else:
-            body = heads[i] + payload[i]
-            frame += len(body).to_bytes(4, 'big') + body
-    return frame
+            payload[fi][si] = out_h[off:off + int(ln)].tobytes()
+    frames = []
+    for fi, secs in enumerate(frames_sections):
+        blob = b''
+        for si in range(4):
+            if secs[si] is None:
+                blob += (0).to_bytes(4, 'big')
+            else:
+                body = heads[fi][si] + payload[fi][si]
+                blob += len(body).to_bytes(4, 'big') + body
+        frames.append(blob)
+    return frames
+
+
+def finalize_frame(sections):
+    return finalize_frames([sections])[0]
 
 
 class ArithmeticCoder():
@@ -94,29 +105,44 @@ class ArithmeticCoder():
         _, cdf = self.balle_pdf_estim.cdf_table(dev, want_float=True)
         return cdf.reshape(1, -1, 1, 1, abi.LP)
 
-    # ---- in-memory API (device tensors in NHWC) -----------------------------------------------
+    # ---- in-memory API (device tensors in NHWC, batch of frames along n) ------------------------
     def pend_z(self, q_z):
-        return PendingSection('pmf', q_z, table=self.z_table(q_z.device))
+        """q_z [n,h,w,c] -> list of n PendingSection"""
+        table = self.z_table(q_z.device)
+        return [PendingSection('pmf', q_z[i:i + 1], table=table) for i in range(q_z.shape[0])]
 
     def pend_y(self, q_y, sigma):
-        return PendingSection('laplace', q_y, sigma=sigma)
+        flags = ops.nonzero_flags(q_y)  # async, no sync here
+        return [PendingSection('laplace', q_y[i:i + 1], sigma=sigma[i:i + 1], flags=flags[i])
+                for i in range(q_y.shape[0])]
 
-    def decode_z(self, payload, n, h, w, c, device):
-        """payload bytes -> q_z int16 NHWC [n,h,w,c] (pmf mode, all channels)."""
-        sym = ops.range_decode([payload], [self.z_table(device)], [c * n * h * w], [n * h * w])[0]
-        return ops.scatter_symbols(sym, n * h * w, c, list(range(c))).view(n, h, w, c)
+    def decode_z(self, payloads, h, w, c, device):
+        """list of n payloads -> q_z int16 NHWC [n,h,w,c] (pmf mode, all channels); the n streams
+        are decoded concurrently."""
+        n, npix = len(payloads), h * w
+        syms = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n)
+        maps = list(range(c))
+        return torch.stack([ops.scatter_symbols(s, npix, c, maps).view(h, w, c) for s in syms])
 
-    def decode_y(self, payload, sigma):
-        """payload bytes + sigma NHWC -> q_y int16 NHWC (zero maps restored)."""
+    def decode_y(self, payloads, sigma):
+        """list of n payloads + sigma [n,h,w,c] -> q_y int16 [n,h,w,c] (zero maps restored)."""
         n, h, w, c = sigma.shape
-        n_maps = payload[0]
-        maps = list(payload[1:1 + n_maps])
-        npix = n * h * w
-        if n_maps == 0:
-            return torch.zeros((n, h, w, c), dtype=torch.int16, device=sigma.device)
-        rows = ops.laplace_cdf_rows(sigma, maps)
-        sym = ops.range_decode([payload[1 + n_maps:]], [rows], [n_maps * npix], [0])[0]
-        return ops.scatter_symbols(sym, npix, c, maps).view(n, h, w, c)
+        npix = h * w
+        maps = [list(p[1:1 + p[0]]) for p in payloads]
+        row_offs, total = [], 0
+        for m in maps:
+            row_offs.append(total)
+            total += len(m) * npix
+        live = [i for i in range(n) if maps[i]]
+        syms = {}
+        if live:
+            rows = torch.empty((total, abi.CDF_ROW), dtype=torch.int16, device=sigma.device)
+            for i in live:
+                ops.laplace_cdf_rows(sigma[i:i + 1], maps[i], out=rows, row_off=row_offs[i])
+            dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], rows,
+                                   [row_offs[i] for i in live], [len(maps[i]) * npix for i in live], [0] * len(live))
+            syms = dict(zip(live, dec))
+        return torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
 
     # ---- path-based API with the reference's signatures (NCHW float tensors, one file per frame) --
     def encode(self, param):
@@ -132,7 +158,7 @@ class ArithmeticCoder():
         if not path.endswith(BITSTREAM_SUFFIX):
             path += BITSTREAM_SUFFIX
         q = ops.to_nhwc(x).to(torch.int16)
-        sec = self.pend_y(q, ops.to_nhwc(sigma)) if mode == 'laplace' else self.pend_z(q)
+        sec = (self.pend_y(q, ops.to_nhwc(sigma)) if mode == 'laplace' else self.pend_z(q))[0]
         slots = [None] * 4
         slots[SECTION_NAMES.index(latent_name)] = sec
         body = split_sections(finalize_frame(slots))[SECTION_NAMES.index(latent_name)]
@@ -156,8 +182,8 @@ class ArithmeticCoder():
         with open(path, 'rb') as f:
             payload = split_sections(f.read())[SECTION_NAMES.index(latent_name)]
         if mode == 'laplace':
-            q = self.decode_y(payload, ops.to_nhwc(sigma))
+            q = self.decode_y([payload], ops.to_nhwc(sigma))
         else:
             b, c, h, w = data_dim
-            q = self.decode_z(payload, b, h, w, c, torch.device(device))
+            q = self.decode_z([payload], h, w, c, torch.device(device))
         return ops.to_nchw_view(q.float())

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode throughput of the AIVC hot path on MI355X.
+
+One "step" = encode + decode of one intra-period unit (33 frames: I, P, 31 hierarchical B) of
+synthetic 1920x1080 8-bit YUV 4:2:0 video under random-access coding `1_GOP_32` (BASELINE.json
+configs[3], the configuration the metric is quoted on; it fits one GPU).  Units are independent
+(own I frame), so with N GPUs each rank codes its own units (weak scaling, no data-path collective;
+one broadcast of the weights at start).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline      dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic FLOPs per launch / average
+                launch duration, measured with HIP events on the launch stream during an extra,
+                untimed, instrumented step.
+  cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+VARIANT_NAMES = {0: 'conv_direct_kernel', 100: 'conv_mfma<conv,128x128>', 101: 'conv_mfma<conv,64x64>',
+                 102: 'conv_mfma<conv,256x64>', 103: 'conv_mfma<conv,128x32>', 110: 'conv_mfma<tconv,128x128>',
+                 111: 'conv_mfma<tconv,64x64>', 112: 'conv_mfma<tconv,256x64>', 113: 'conv_mfma<tconv,128x32>',
+                 120: 'conv_mfma<gdn,128x128>', 121: 'conv_mfma<gdn,64x64>', 122: 'conv_mfma<gdn,256x64>',
+                 123: 'conv_mfma<gdn,128x32>'}
+
+
+def gpu_synthetic_unit(width, height, n_frames, t0, device, seed):
+    """Same moving pattern as aivc_amd.synth.synthetic_video, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    hc, wc = (height + 1) // 2, (width + 1) // 2
+    xs = torch.arange(width, device=device).float()[None, :]
+    ys = torch.arange(height, device=device).float()[:, None]
+    xc = torch.arange(wc, device=device).float()[None, :]
+    yc = torch.arange(hc, device=device).float()[:, None]
+    two_pi = 6.283185307179586
+    out = []
+    for t in range(t0, t0 + n_frames):
+        y = 128 + 64 * torch.sin(two_pi * (xs + 3 * t) / 97) + 48 * torch.cos(two_pi * (ys - 2 * t) / 61)
+        u = 128 + 40 * torch.sin(two_pi * (xc + 1.5 * t) / 53) * torch.cos(two_pi * yc / 47)
+        v = 128 + 40 * torch.cos(two_pi * (yc - t) / 41) * torch.sin(two_pi * xc / 59)
+        f = {}
+        for k, a in (('y', y), ('u', u), ('v', v)):
+            a = a + 4 * torch.randn(a.shape, device=device, generator=g)
+            f[k] = a.round().clamp(0, 255).to(torch.uint8).unsqueeze(0).contiguous()
+        out.append(f)
+    return out
+
+
+def cpu_baseline(width, height, model):
+    """Oracle (CPU port) encode+decode of an I + P pair; falls back to a quarter-size frame when a
+    probe says the full-size sample would exceed ~40 s."""
+    import numpy as np
+    from aivc_amd import synth
+    from oracle import codec as ocodec
+    from oracle import oracle as orc
+    from oracle import spec as ospec
+    orc.lib()
+    cores = os.cpu_count() or 1
+    spec = ospec.export_model(model)
+    # probe: one 3x3 128->128 conv on a 135x240 map (9.6 GFLOP)
+    x = np.random.default_rng(0).standard_normal((1, 135, 240, 128), dtype=np.float32)
+    w = np.random.default_rng(1).standard_normal((128, 3, 3, 128), dtype=np.float32) * 0.03
+    t = time.time()
+    orc.conv2d(x, w, None, pad=1)
+    gflops = 9.56 / max(time.time() - t, 1e-6)
+    est_full = 3200.0 / gflops  # ~3.2 TFLOP for I + P at 1080p with the default widths
+    scale = 1
+    w_s, h_s = width, height
+    if est_full > 40.0:
+        scale, w_s, h_s = 4, width // 2, height // 2
+    frames = synth.synthetic_video(w_s, h_s, 2, seed=11)
+    t = time.time()
+    blob, _ = ocodec.encode_video(spec, frames, 'LDP_1')
+    ocodec.decode_video(spec, blob)
+    dt = time.time() - t
+    fps = 2.0 / dt / scale
+    sample = ('oracle encode+decode of 2 frames (I+P, LDP_1) at %dx%d in %.1f s on %d threads'
+              % (w_s, h_s, dt, cores))
+    if scale != 1:
+        sample += '; fps divided by %d (pixel ratio to %dx%d)' % (scale, width, height)
+    return {'value': round(fps, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'sample': sample,
+            'probe_conv_gflops': round(gflops, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--width', type=int, default=1920)
+    ap.add_argument('--height', type=int, default=1080)
+    ap.add_argument('--gop', type=str, default='1_GOP_32')
+    ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from aivc_amd import ops, synth
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    from aivc_amd.models import arch
+    from aivc_amd.parallel import broadcast_model
+    widths = arch.TINY_WIDTHS if args.tiny else arch.DEFAULT_WIDTHS
+    seed = 1234
+    model = synth.make_model(widths, seed=seed, device=dev)
+    synth.calibrate_operating_point(model, dev)
+    if world > 1:
+        broadcast_model(model)  # the one collective: weights over RCCL/xGMI
+    fc = model.frame_codec()
+    unit = len(generate_gop_struct(args.gop))
+    n_total = args.warmup + args.steps + 1
+    # unit u of this rank's share = global unit (rank + u * world)
+    clips = [gpu_synthetic_unit(args.width, args.height, unit, (rank + i * world) * unit, dev, 666 + rank + i * world)
+             for i in range(n_total)]
+    torch.cuda.synchronize()
+
+    stats = {'enc_s': 0.0, 'dec_s': 0.0, 'bytes': 0}
+
+    def step(i, timed=False):
+        with torch.no_grad():
+            t0 = time.time()
+            enc = fc.encode_video(clips[i], args.gop)
+            blob = fc.assemble_video(enc)
+            if timed:
+                torch.cuda.synchronize()
+                t1 = time.time()
+            dec, _, _, _ = fc.decode_video(blob, dev)
+            if timed:
+                torch.cuda.synchronize()
+                stats['enc_s'] += t1 - t0
+                stats['dec_s'] += time.time() - t1
+                stats['bytes'] += len(blob)
+        return enc, dec
+
+    closed_loop = True
+    for i in range(args.warmup):
+        enc, dec = step(i)
+        rec = [r for g in enc['recs'] for r in g][:len(dec)]
+        closed_loop &= all(torch.equal(d[k], e[k]) for d, e in zip(dec, rec) for k in 'yuv')
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i, timed=True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        ops.PROFILE = []
+        step(n_total - 1)
+        torch.cuda.synchronize()
+        per = {}
+        for variant, flops, e0, e1 in ops.PROFILE:
+            d = per.setdefault(variant, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += flops
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        ops.PROFILE = None
+        mf = {v: d for v, d in per.items() if v >= 100}
+        if mf:
+            dom = max(mf, key=lambda v: mf[v][2])
+            cnt, fl, sec = mf[dom]
+            all_fl = sum(d[1] for d in mf.values())
+            all_sec = sum(d[2] for d in mf.values())
+            roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
+                        'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                        'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 2),
+                        'gflop_per_launch': round(fl / cnt / 1e9, 3),
+                        'all_mfma_conv': {'achieved': round(all_fl / all_sec / 1e12, 2),
+                                          'frac': round(all_fl / all_sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                          'tflop_per_step': round(all_fl / 1e12, 3),
+                                          'kernel_s_per_step': round(all_sec, 4)},
+                        'per_variant': {VARIANT_NAMES.get(v, str(v)): {'launches': d[0], 'tflops': round(d[1] / d[2] / 1e12, 2),
+                                                                       'ms_total': round(d[2] * 1e3, 2)}
+                                        for v, d in sorted(per.items())}}
+
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.width, args.height, model)
+
+    if rank == 0:
+        frames = world * args.steps * unit
+        out = {
+            'metric': 'encode+decode fps @1080p YUV420 (RA GOP32)',
+            'value': round(frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: one %d-frame intra-period unit encoded + '
+                                   'decoded per step per GPU; synthetic random-init stand-in for model ms_ssim-4 '
+                                   '(widths %s); units sharded across GPUs' % (args.width, args.height, args.gop, unit, widths),
+                       'frames_per_step': unit, 'parallelism': 'unit-sharded x%d' % world},
+            'encode_fps_rank0': round(args.steps * unit / stats['enc_s'], 3),
+            'decode_fps_rank0': round(args.steps * unit / stats['dec_s'], 3),
+            'bytes_per_frame': round(stats['bytes'] / (args.steps * unit), 1),
+            'closed_loop_ok': bool(closed_loop),
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        if args.tiny:
+            out['invalid'] = 'tiny debug model'
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -98,6 +98,11 @@ typedef struct aivc_conv_params {
  *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
+/* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,
+ * otherwise 100 + 10 * template-mode (0 conv, 1 tconv, 2 gdn) + tile id (0: 128x128, 1: 64x64,
+ * 2: 256x64, 3: 128x32).  Negative = error code.  Used by bench.py to attribute launch times. */
+int aivc_conv2d_variant(const aivc_conv_params *p);
+
 /* GDN re-parameterisation, done once per layer instead of once per call:
  *   beta_eff[i]    = max(beta[i],  beta_bound)^2  - pedestal
  *   gamma_eff[i,j] = max(gamma[i,j], gamma_bound)^2 - pedestal       (all fp32)
@@ -197,7 +202,7 @@ int aivc_dequantize(const int16_t *q, const float *mu, const float *gain_dec, si
 #define AIVC_CDF_ROW 520 /* uint16 per stored CDF row (514 used, 1040 B = 65 x 16 B) */
 #define AIVC_BALLE_PARAMS 43 /* floats per channel, see aivc_balle_cdf_table */
 #define AIVC_MAX_MAPS 256
-#define AIVC_RC_MAX_STREAMS 8
+#define AIVC_RC_MAX_STREAMS 64
 
 /* Factorised-prior CDF table (BallePdfEstim.cdf at k - 256.5, k = 0..513), quantised like
  * torchac:  u16 = (uint16)(rint(cdf * 65023) + k).

@@ -162,7 +162,7 @@ def test_cdf_kernels_bit_exact(oracle, cuda):
     eq(ops.laplace_bounds(T(sig, cuda), T(q, cuda), maps), oracle.laplace_bounds(sig, q, maps))
     qz = rng.integers(-5, 6, (1, 3, 4, 6)).astype(np.int16)
     eq(ops.table_bounds(T(table.view(np.int16), cuda), T(qz, cuda)), oracle.table_bounds(table, qz))
-    flags = ops.nonzero_flags(T(q, cuda)).cpu().numpy()
+    flags = ops.nonzero_flags(T(q, cuda)).cpu().numpy()[0]
     assert [i for i in range(8) if flags[i]] == oracle.nonzero_maps(q)
 
 
@@ -187,7 +187,7 @@ def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
     ref_sym = oracle.range_decode(ref_bytes, rows, n_sym)
     want = (q.reshape(-1, c).T.reshape(-1)[:n_sym].astype(np.int32) + 256).astype(np.uint16)
     np.testing.assert_array_equal(ref_sym, want)
-    got_sym = ops.range_decode([ref_bytes], [T(rows.view(np.int16), cuda)], [n_sym], [0])[0]
+    got_sym = ops.range_decode([ref_bytes], T(rows.view(np.int16), cuda), [0], [n_sym], [0])[0]
     eq(got_sym, ref_sym)
 
 
@@ -202,7 +202,7 @@ def test_range_coder_pmf_and_scatter(oracle, cuda):
     out, lens, _ = ops.range_encode([T(bounds.view(np.int32), cuda)])
     assert out.cpu().numpy()[:int(lens.cpu()[0])].tobytes() == ref_bytes
     n_sym = qz.size
-    sym = ops.range_decode([ref_bytes], [T(table.view(np.int16), cuda)], [n_sym], [42])[0]
+    sym = ops.range_decode([ref_bytes], T(table.view(np.int16), cuda), [0], [n_sym], [42])[0]
     eq(sym, oracle.range_decode(ref_bytes, table, n_sym, plane=42))
     qback = ops.scatter_symbols(sym, 42, 5, list(range(5)))
     eq(qback, qz.reshape(42, 5))
@@ -210,3 +210,31 @@ def test_range_coder_pmf_and_scatter(oracle, cuda):
     maps = [1, 4]
     s2 = T((qz.reshape(42, 5)[:, maps].T.reshape(-1).astype(np.int32) + 256).astype(np.uint16).view(np.int16), cuda)
     eq(ops.scatter_symbols(s2, 42, 5, maps), oracle.scatter_symbols(s2.cpu().numpy().view(np.uint16), 42, 5, maps))
+
+
+def test_range_coder_many_streams_concurrently(oracle, cuda):
+    """70 independent streams (> 64 per launch) with different lengths: batched == one by one."""
+    from aivc_amd import ops
+    rng = np.random.default_rng(21)
+    c, bl, pl, rows_all, offs, ns, want = 1, [], [], [], [], [], []
+    total = 0
+    for i in range(70):
+        n = int(rng.integers(1, 700))
+        sig = np.exp(rng.uniform(-3, 3, (1, 1, n, 1))).clip(1e-4, 148).astype(np.float32)
+        q = np.clip(np.rint(rng.laplace(0, 1, sig.shape) * sig), -256, 255).astype(np.int16)
+        b = oracle.laplace_bounds(sig, q, [0])
+        bl.append(T(b.view(np.int32), cuda))
+        pl.append(oracle.range_encode(b))
+        rows_all.append(oracle.laplace_cdf_rows(sig, [0]))
+        offs.append(total)
+        total += n
+        ns.append(n)
+        want.append((q.reshape(-1).astype(np.int32) + 256).astype(np.uint16))
+    out, lens, o = ops.range_encode(bl)
+    out_h, lens_h = out.cpu().numpy(), lens.cpu().numpy()
+    for i in range(70):
+        assert out_h[o[i][0]:o[i][0] + lens_h[i]].tobytes() == pl[i]
+    rows = T(np.concatenate(rows_all).view(np.int16), cuda)
+    dec = ops.range_decode(pl, rows, offs, ns, [0] * 70)
+    for i in range(70):
+        eq(dec[i], want[i])
