@@ -1,0 +1,112 @@
+"""Frame / GOP / video decoder with the reference's class and function names
+(src/real_life/decode.py).  Decoder.decode keeps the reference's dictionary contract (float YUV
+dicts, one bitstream file per frame); decode_one_video reads the container and writes planar YUV
+directly (the reference's PNG triplets + per-frame `dd` forks are out of scope)."""
+import time
+
+import numpy as np
+import torch
+from torch.nn import Module
+
+from ..codec import FrameCodec
+from ..func_util.console_display import print_log_msg
+from ..func_util.nn_util import get_value
+from ..models.full_net import _to_float_dic, _to_u8_planes
+from .utils import BITSTREAM_SUFFIX
+
+
+class ConditionalDecoder(Module):
+    """Decoder half of a ConditionalNet (src/real_life/decode.py:752-898): shares the sub-modules."""
+
+    def __init__(self, param):
+        super().__init__()
+        net = get_value('conditional_net', param, {'conditional_net': None})
+        self.net = net
+        self.g_s, self.h_s = net.g_s, net.h_s
+        self.g_a_ref = getattr(net, 'g_a_ref', None)
+        self.pdf_y, self.pdf_z, self.pdf_parameterizer = net.pdf_y, net.pdf_z, net.pdf_parameterizer
+        self.nb_ft_shortcut_out, self.nb_ft_y, self.nb_ft_z = net.out_c_shortcut_y, net.nb_ft_y, net.nb_ft_z
+        self.gain_I, self.flag_gain_p_b = net.gain_I, net.flag_gain_p_b
+        if self.flag_gain_p_b:
+            self.gain_P, self.gain_B = net.gain_P, net.gain_B
+        self.ac = net.ac
+
+
+class CodecNetDecoder(Module):
+    def __init__(self, param):
+        super().__init__()
+        self.codec_dec = ConditionalDecoder({'conditional_net': get_value('codec_net', param, {'codec_net': None}).codec_net})
+
+
+class MOFNetDecoder(Module):
+    def __init__(self, param):
+        super().__init__()
+        self.mofnet_dec = ConditionalDecoder({'conditional_net': get_value('mofnet', param, {'mofnet': None}).mode_net})
+
+
+class Decoder(Module):
+    """Entire decoder, built from a complete FullNet (src/real_life/decode.py:429-580)."""
+
+    def __init__(self, param):
+        super().__init__()
+        full_net = get_value('full_net', param, {'full_net': None})
+        self.full_net = full_net
+        self.codec_net_dec = CodecNetDecoder({'codec_net': full_net.codec_net})
+        self.mofnet_dec = MOFNetDecoder({'mofnet': full_net.mode_net})
+        self.motion_compensation = full_net.motion_compensation
+        self.in_layer, self.out_layer = full_net.in_layer, full_net.out_layer
+
+    def decode(self, param):
+        """{'prev_dic','next_dic','frame_type','bitstream_path','data_dim','idx_rate','device'} ->
+        decoded frame as a float YUV dict holding 8-bit levels."""
+        default = {'prev_dic': None, 'next_dic': None, 'frame_type': None, 'bitstream_path': None, 'data_dim': None,
+                   'flag_bitstream_debug': False, 'idx_rate': 0., 'device': 'cuda:0'}
+        dev = torch.device(get_value('device', param, default))
+        path = get_value('bitstream_path', param, default)
+        if not path.endswith(BITSTREAM_SUFFIX):
+            path += BITSTREAM_SUFFIX
+        with open(path, 'rb') as f:
+            frame_bytes = f.read()
+
+        def planes(d):
+            return None if d is None else _to_u8_planes(d, dev)
+        fc = FrameCodec(self.full_net)
+        rec = fc.decode_frame(frame_bytes, planes(get_value('prev_dic', param, default)),
+                              planes(get_value('next_dic', param, default)), get_value('frame_type', param, default),
+                              get_value('data_dim', param, default), get_value('idx_rate', param, default), dev)
+        return _to_float_dic(rec)
+
+
+def write_yuv(frames, path):
+    """frames: list of dicts of uint8 tensors/arrays [1,h,w] -> planar I420 file."""
+    with open(path, 'wb') as f:
+        for fr in frames:
+            for k in 'yuv':
+                a = fr[k]
+                a = a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                f.write(np.ascontiguousarray(a).tobytes())
+
+
+def decode_one_video(param):
+    default = {'decoder': None, 'bitstream_path': '', 'device': 'cuda:0', 'out_file': '', 'flag_bitstream_debug': False}
+    decoder = get_value('decoder', param, default).eval()
+    path = get_value('bitstream_path', param, default)
+    dev = torch.device(get_value('device', param, default))
+    out_file = get_value('out_file', param, default)
+    print_log_msg('INFO', 'Bitstream path', '', path)
+    with open(path, 'rb') as f:
+        blob = f.read()
+    print_log_msg('INFO', 'Start decoding', '', '')
+    t0 = time.time()
+    with torch.no_grad():
+        frames, data_dim, first, last = FrameCodec(decoder.full_net).decode_video(blob, dev)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    n = last - first + 1
+    print_log_msg('INFO', 'Decoding done', '', '')
+    print_log_msg('RESULT', 'Number of frames', '[frame]', int(n))
+    print_log_msg('RESULT', 'Decoding time', '[s]', '%.1f' % dt)
+    print_log_msg('RESULT', 'Decoding FPS', '[frame/s]', '%.1f' % (n / dt))
+    if out_file:
+        write_yuv(frames, out_file)
+    return frames

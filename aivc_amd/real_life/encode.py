@@ -1,0 +1,81 @@
+"""encode(param) with the reference's signature and RESULT lines (src/real_life/encode.py), reading
+planar YUV directly instead of PNG triplets."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..codec import FrameCodec
+from ..func_util.console_display import print_log_msg
+from ..func_util.nn_util import get_value
+
+
+def parse_yuv_name(path):
+    """'<Name>_<W>x<H>_<fps>_420.yuv' -> (w, h)  (src/format_conversion/utils.py:45-72)"""
+    for tok in os.path.basename(path).split('_'):
+        if 'x' in tok:
+            a, b = tok.split('x')
+            if a.isdigit() and b.isdigit():
+                return int(a), int(b)
+    raise ValueError('cannot parse WxH from %s' % path)
+
+
+def read_yuv(path, first=0, last=-1, device=None):
+    w, h = parse_yuv_name(path)
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    fsize = h * w + 2 * hc * wc
+    n_total = os.path.getsize(path) // fsize
+    last = n_total - 1 if last < 0 else last
+    frames = []
+    with open(path, 'rb') as f:
+        f.seek(first * fsize)
+        for _ in range(first, last + 1):
+            buf = np.frombuffer(f.read(fsize), np.uint8)
+            fr = {'y': buf[:h * w].reshape(1, h, w), 'u': buf[h * w:h * w + hc * wc].reshape(1, hc, wc),
+                  'v': buf[h * w + hc * wc:].reshape(1, hc, wc)}
+            frames.append({k: torch.from_numpy(v.copy()).to(device) for k, v in fr.items()})
+    return frames, first, last
+
+
+def encode(param):
+    default = {'model': None, 'sequence_path': '', 'GOP_struct_name': '', 'GOP_struct': None, 'idx_rate': 0.,
+               'final_file': '', 'flag_bitstream_debug': False, 'idx_starting_frame': 0, 'idx_end_frame': -1}
+    model = get_value('model', param, default)
+    seq = get_value('sequence_path', param, default)
+    gop_name = get_value('GOP_struct_name', param, default)
+    final_file = get_value('final_file', param, default)
+    first = get_value('idx_starting_frame', param, default)
+    last = get_value('idx_end_frame', param, default)
+    dev = next(model.parameters()).device
+    if first > last and last != -1:
+        print('ERROR: First frame index bigger than last frame index')
+        return
+    frames, first, last = read_yuv(seq, first, last, dev)
+    print_log_msg('INFO', 'Start encoding', '', '')
+    t0 = time.time()
+    fc = FrameCodec(model)
+    with torch.no_grad():
+        enc = fc.encode_video(frames, gop_name, idx_starting_frame=first, idx_end_frame=last,
+                              idx_rate=get_value('idx_rate', param, default))
+        blob = fc.assemble_video(enc)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    parent = os.path.dirname(final_file)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    with open(final_file, 'wb') as f:
+        f.write(blob)
+    n = last - first + 1
+    recs = [r for g in enc['recs'] for r in g][:n]
+    se = sum(float(((r[k].float() - f[k].float()) ** 2).sum()) for r, f in zip(recs, frames) for k in 'yuv')
+    cnt = sum(f[k].numel() for f in frames for k in 'yuv')
+    psnr = 10 * np.log10(255.0 ** 2 / max(se / cnt, 1e-12))
+    print_log_msg('INFO', 'Encoding done', '', '')
+    print_log_msg('INFO', 'Bitstream path', '', final_file)
+    print_log_msg('RESULT', 'Number of frames', '[frame]', int(n))
+    print_log_msg('RESULT', 'Encoding/decoding time', '[s]', '%.1f' % dt)
+    print_log_msg('RESULT', 'Encoding/decoding FPS', '[frame/s]', '%.1f' % (n / dt))
+    print_log_msg('RESULT', 'Estimated PSNR', '[dB]', '%.4f' % psnr)
+    print_log_msg('RESULT', 'Real rate', '[byte]', len(blob))
+    return {'real_rate_byte': len(blob), 'psnr': psnr, 'nb_frames_to_code': n}

@@ -1,0 +1,124 @@
+"""CPU-side checks: the C ABI library exports every symbol the header declares, module aliases make
+full-module pickles loadable, CLI mapping, product path fails loudly without a GPU."""
+import ctypes
+import io
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'aivc_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|const char \*)\s*(aivc_\w+)\s*\(', src)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib_path = os.path.join(ROOT, 'aivc_amd', 'lib', 'libaivc_hip.so')
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+        g.build_hip()
+    lib = ctypes.CDLL(lib_path)  # loads without a GPU (no compute call is made)
+    names = header_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), 'libaivc_hip.so does not export %s' % n
+    lib.aivc_abi_version.restype = ctypes.c_int
+    from aivc_amd import abi
+    assert lib.aivc_abi_version() == abi.ABI_VERSION
+    # every prototype bound by abi.py is declared in the header and vice versa
+    assert set(abi.PROTOTYPES) | {'aivc_abi_version', 'aivc_last_error', 'aivc_conv2d_variant'} == set(names)
+
+
+def test_oracle_exports_ref_twins(oracle):
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libaivc_oracle.so'))
+    from aivc_amd import abi
+    for n in abi.PROTOTYPES:
+        assert hasattr(lib, n + '_ref')
+
+
+def test_argument_validation_without_gpu():
+    """error paths return codes instead of crashing (no kernel is launched)."""
+    from aivc_amd import _lib, abi
+    fns = _lib.load()
+    assert fns['aivc_conv2d'](None, None) == -1
+    p = abi.ConvParams(abi.MODE_CONV, 7, 1, 3, 1, 8, 8, 4, 8, 8, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    assert fns['aivc_conv2d'](ctypes.byref(p), None) == -2  # ksize 7 unsupported
+    p = abi.ConvParams(abi.MODE_CONV, 3, 1, 1, 1, 8, 8, 3, 8, 8, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    assert fns['aivc_conv2d'](ctypes.byref(p), None) == -1  # c_in not a multiple of 4
+    p = abi.ConvParams(abi.MODE_CONV, 3, 2, 1, 1, 9, 9, 4, 4, 5, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    assert fns['aivc_conv2d'](ctypes.byref(p), None) == -1  # wrong output size
+    assert fns['aivc_conv2d_variant'](ctypes.byref(abi.ConvParams(
+        abi.MODE_CONV, 3, 1, 1, 1, 270, 480, 128, 270, 480, 128, 0, 0, 0, 1, 1, None, None, None, 1))) == 100
+
+
+def test_product_path_refuses_cpu_tensors():
+    from aivc_amd import ops
+    from aivc_amd._lib import AivcNativeError
+    with pytest.raises(AivcNativeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 3, 3, 4))
+    from aivc_amd.layers.misc.custom_conv_layers import CustomConvLayer
+    with pytest.raises(AivcNativeError):
+        CustomConvLayer(3, 4, 4)(torch.zeros(1, 4, 8, 8))
+    from aivc_amd.cli_common import resolve_device
+    with pytest.raises(SystemExit):
+        resolve_device(True)
+
+
+def test_full_module_pickle_round_trip_through_reference_module_names():
+    """A reference .pt is a pickle of the whole nn.Module whose classes live in `layers.*`,
+    `models.*`: the aliases must resolve them to this package."""
+    import aivc_amd
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    aivc_amd.install_aliases()
+    model = synth.make_model(arch.TINY_WIDTHS, seed=3)
+    for net in (model.codec_net.codec_net, model.mode_net.mode_net):
+        net.ac = None  # not pickled upstream either
+
+    # write the pickle with the REFERENCE's module paths (what a real .pt contains)
+    classes = {type(m) for m in model.modules() if type(m).__module__.startswith('aivc_amd.')}
+    saved = {c: c.__module__ for c in classes}
+    try:
+        for c in classes:
+            c.__module__ = c.__module__[len('aivc_amd.'):]
+        buf = io.BytesIO()
+        torch.save(model, buf)
+    finally:
+        for c, m in saved.items():
+            c.__module__ = m
+    raw = buf.getvalue()
+    assert b'layers.misc.custom_conv_layers' in raw and b'aivc_amd.layers' not in raw
+    loaded = torch.load(io.BytesIO(raw), map_location='cpu', weights_only=False)
+    assert type(loaded).__name__ == 'FullNet'
+    sd_a, sd_b = model.state_dict(), loaded.state_dict()
+    assert sd_a.keys() == sd_b.keys()
+    assert all(torch.equal(sd_a[k], sd_b[k]) for k in sd_a)
+    # the attribute contract the reference's decoder reads (src/real_life/decode.py:447-453,770-795)
+    cn = loaded.codec_net.codec_net
+    for attr in ('g_s', 'h_s', 'g_a_ref', 'pdf_y', 'pdf_z', 'pdf_parameterizer', 'out_c_shortcut_y', 'nb_ft_y',
+                 'nb_ft_z', 'gain_I', 'flag_gain_p_b', 'gain_P', 'gain_B'):
+        assert hasattr(cn, attr)
+    for attr in ('codec_net', 'mode_net', 'motion_compensation', 'in_layer', 'out_layer', 'model_param'):
+        assert hasattr(loaded, attr)
+    assert 'lambda_tradeoff' in loaded.model_param
+
+
+def test_cli_gop_mapping():
+    from aivc_amd.aivc import gop_name
+    assert gop_name('AI', 32, 32) == '1_GOP_0'
+    assert gop_name('LDP', 32, 8) == 'LDP_8'
+    assert gop_name('RA', 16, 32) == '2_GOP_16'   # the reference's sanity_script.sh setting
+    assert gop_name('RA', 32, 32) == '1_GOP_32'
+    with pytest.raises(SystemExit):
+        gop_name('RA', 16, 24)
+
+
+def test_section_framing_without_gpu():
+    from aivc_amd.real_life.bitstream import split_sections
+    frame = (0).to_bytes(4, 'big') * 2 + (3).to_bytes(4, 'big') + b'abc' + (1).to_bytes(4, 'big') + b'\x00'
+    assert split_sections(frame) == [b'', b'', b'abc', b'\x00']
