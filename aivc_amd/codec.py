@@ -13,7 +13,7 @@ from . import ops
 from .func_util.GOP_structure import FRAME_B, FRAME_I, FRAME_P, coding_levels, generate_gop_struct
 from .real_life import cat_binary_files as container
 from .real_life import header as hdr
-from .real_life.bitstream import finalize_frames, split_sections
+from .real_life.bitstream import finalize_frames, launch_finalize, split_sections
 
 
 def frame_index(name):
@@ -122,6 +122,11 @@ class FrameCodec:
     # depend on earlier levels, so they are pushed through the networks as one batch and their
     # entropy streams are coded concurrently.  Frames are stored in display order in the container,
     # so this yields the same bytes as the reference's depth-first order.
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _chunks(self, gop, level, unit_ids):
         """(frame type, [(unit, frame name), ...]) batches of at most max_batch same-type frames of one
         dependency level (a level of a chained GOP mixes P and B frames)."""
@@ -138,6 +143,8 @@ class FrameCodec:
         rec = [dict() for _ in units]
         fbytes = [dict() for _ in units]
         data_dim = None
+        side = self._side_stream()
+        jobs = []
         for level in coding_levels(gop):
             pending = []
             for ftype, chunk in self._chunks(gop, level, range(len(units))):
@@ -148,9 +155,12 @@ class FrameCodec:
                 for (u, f), r in zip(chunk, out['rec']):
                     rec[u][f] = r
                 pending.append((chunk, out['sections']))
-            # entropy-code the whole level in one go (one sync, one batched launch)
+            # entropy-code the whole level on the side stream (one sync for the map flags, one batched
+            # launch); the next level's transforms run meanwhile on the main stream
             all_secs = [s for _, secs in pending for s in secs]
-            for (u, f), b in zip([it for chunk, _ in pending for it in chunk], finalize_frames(all_secs)):
+            jobs.append(([it for chunk, _ in pending for it in chunk], launch_finalize(all_secs, side)))
+        for items, job in jobs:
+            for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b
         head = hdr.gop_header_bytes(gop_name, idx_rate)
         blobs = [container.pack_gop(head, [fbytes[u][f] for f in names]) for u in range(len(units))]

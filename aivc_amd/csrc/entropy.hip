@@ -264,18 +264,20 @@ struct BitSrc {
   }
 };
 
-constexpr int DEC_G = 8;  // symbols per prefetch group
+constexpr int DEC_G = 8;      // symbols per prefetch group
+constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
 
 struct RowRegs {
-  uint4 e;      // 8 consecutive uint16 CDF entries: 8*lane .. 8*lane+7
+  uint4 e;      // 8 consecutive uint16 CDF entries: 8*lane .. 8*lane+7     (full-row search)
   uint32_t nx;  // entry 8*lane+8
+  uint32_t ew;  // entry DEC_WIN0 + lane                                      (window search)
 };
 
-// #lanes whose CDF entry e satisfies e <= count, without computing count:
+// lanes whose CDF entry e satisfies e <= count, without computing count:
 //   e <= floor(num / span)  <=>  e * span <= num  <=>  e * (span - 1) + e <= num
-__device__ __forceinline__ uint32_t le_count(uint32_t e, uint32_t hl, uint64_t num) {
+__device__ __forceinline__ unsigned long long le_mask(uint32_t e, uint32_t hl, uint64_t num) {
   const uint64_t prod = (uint64_t)e * (uint64_t)hl + (uint64_t)e;
-  return (uint32_t)__builtin_popcountll(__ballot(prod <= num));
+  return __ballot(prod <= num);
 }
 
 __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
   uint32_t low = 0, high = 0xFFFFFFFFu;
   uint32_t value = src.take(32);
 
-  // row bookkeeping for the prefetcher (independent of coder state)
+  // row bookkeeping for the prefetcher (row addresses never depend on coder state)
   uint64_t pf_row = st.row_off;
   uint32_t pf_in_plane = 0;
   auto fetch = [&](RowRegs &r, bool valid) {
@@ -301,82 +303,92 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
       const uint16_t *row = rows + pf_row * AIVC_CDF_ROW;
       r.e = *reinterpret_cast<const uint4 *>(row + lane * 8);
       r.nx = row[lane * 8 + 8];
+      r.ew = row[DEC_WIN0 + lane];
       if (st.plane == 0) {
         pf_row++;
       } else if (++pf_in_plane == st.plane) {
         pf_in_plane = 0;
         pf_row++;
       }
-    } else {
-      r.e = make_uint4(0, 0, 0, 0);
-      r.nx = 0;
     }
   };
 
-  RowRegs cur[DEC_G], nxt[DEC_G];
-#pragma unroll
-  for (int g = 0; g < DEC_G; ++g) fetch(cur[g], (uint32_t)g < st.n_sym);
-
   uint32_t mysym = 0;
-  for (uint32_t base = 0; base < st.n_sym; base += DEC_G) {
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g) fetch(nxt[g], base + DEC_G + g < st.n_sym);
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g) {
-      const uint32_t i = base + g;
-      if (i < st.n_sym) {
-        const uint4 e = cur[g].e;
-        const uint32_t hl = high - low;  // span - 1
-        const uint64_t num = ((((uint64_t)value - (uint64_t)low) + 1) << 16) - 1;
-        // entries are strictly increasing over the row: #(entries <= count) = symbol + 1
-        uint32_t total = le_count(e.x & 0xFFFFu, hl, num) + le_count(e.x >> 16, hl, num) +
-                         le_count(e.y & 0xFFFFu, hl, num) + le_count(e.y >> 16, hl, num) +
-                         le_count(e.z & 0xFFFFu, hl, num) + le_count(e.z >> 16, hl, num) +
-                         le_count(e.w & 0xFFFFu, hl, num) + le_count(e.w >> 16, hl, num);
-        uint32_t m = total > 0 ? total - 1 : 0;
-        const int L = (int)(m >> 3);
-        const uint32_t idx = m & 7u;
-        // entries 8L .. 8L+8 of the row as scalars
-        const uint64_t lo64 = (uint64_t)rl(e.x, L) | ((uint64_t)rl(e.y, L) << 32);
-        const uint64_t hi64 = (uint64_t)rl(e.z, L) | ((uint64_t)rl(e.w, L) << 32);
-        const uint32_t nxL = rl(cur[g].nx, L);
-        const uint32_t pos = idx * 16u;
-        uint32_t c_lo = (uint32_t)((pos < 64 ? lo64 >> pos : hi64 >> (pos - 64)) & 0xFFFFu);
-        const uint32_t pos1 = pos + 16u;
-        uint32_t c_hi = idx == 7 ? nxL : (uint32_t)((pos1 < 64 ? lo64 >> pos1 : hi64 >> (pos1 - 64)) & 0xFFFFu);
-        if (m == 511u) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign streams
-          const uint64_t p512 = (uint64_t)nxL * (uint64_t)hl + (uint64_t)nxL;
-          if (p512 <= num) {
-            m = 512u;
-            c_lo = nxL;
-            c_hi = 0x10000u;
-          }
-        }
-        if (lane == (int)(i & 63u)) mysym = m;
-        if ((i & 63u) == 63u || i == st.n_sym - 1) {
-          const uint32_t first = i & ~63u;
-          if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
-        }
-        if (i != st.n_sym - 1) {
-          const uint64_t span = (uint64_t)hl + 1;
-          high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
-          low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
-          const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
-          low <<= n;
-          high = (high << n) | ((1u << n) - 1u);
-          value = (uint32_t)(((uint64_t)value << n)) | src.take(n);
-          const uint32_t y = (low & ~high) << 1;
-          const uint32_t m3 = (uint32_t)__builtin_clz(~y);
-          if (m3 > 0) {
-            low = (low << m3) & 0x7FFFFFFFu;
-            high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
-            value = ((value << m3) ^ 0x80000000u) | src.take(m3);
-          }
+  auto decode_one = [&](const RowRegs &r, uint32_t i) {
+    const uint32_t hl = high - low;  // span - 1
+    const uint64_t num = ((((uint64_t)value - (uint64_t)low) + 1) << 16) - 1;
+    uint32_t m, c_lo, c_hi;
+    // fast path: entries are strictly increasing, so the lanes with entry <= count form a prefix
+    const uint32_t cw = (uint32_t)__builtin_popcountll(le_mask(r.ew, hl, num));
+    if (cw != 0 && cw != 64) {
+      m = (uint32_t)DEC_WIN0 - 1u + cw;
+      c_lo = rl(r.ew, (int)cw - 1);
+      c_hi = rl(r.ew, (int)cw);
+    } else {
+      // symbol outside [-32, 30]: search the whole row (8 entries per lane)
+      const uint4 e = r.e;
+      const uint32_t total =
+          (uint32_t)__builtin_popcountll(le_mask(e.x & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.x >> 16, hl, num)) +
+          (uint32_t)__builtin_popcountll(le_mask(e.y & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.y >> 16, hl, num)) +
+          (uint32_t)__builtin_popcountll(le_mask(e.z & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.z >> 16, hl, num)) +
+          (uint32_t)__builtin_popcountll(le_mask(e.w & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.w >> 16, hl, num));
+      m = total > 0 ? total - 1 : 0;
+      const int L = (int)(m >> 3);
+      const uint32_t idx = m & 7u;
+      const uint64_t lo64 = (uint64_t)rl(e.x, L) | ((uint64_t)rl(e.y, L) << 32);
+      const uint64_t hi64 = (uint64_t)rl(e.z, L) | ((uint64_t)rl(e.w, L) << 32);
+      const uint32_t nxL = rl(r.nx, L);
+      const uint32_t pos = idx * 16u;
+      c_lo = (uint32_t)((pos < 64 ? lo64 >> pos : hi64 >> (pos - 64)) & 0xFFFFu);
+      const uint32_t pos1 = pos + 16u;
+      c_hi = idx == 7 ? nxL : (uint32_t)((pos1 < 64 ? lo64 >> pos1 : hi64 >> (pos1 - 64)) & 0xFFFFu);
+      if (m == 511u) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign streams
+        const uint64_t p512 = (uint64_t)nxL * (uint64_t)hl + (uint64_t)nxL;
+        if (p512 <= num) {
+          m = 512u;
+          c_lo = nxL;
+          c_hi = 0x10000u;
         }
       }
     }
+    if (lane == (int)(i & 63u)) mysym = m;
+    if ((i & 63u) == 63u || i == st.n_sym - 1) {
+      const uint32_t first = i & ~63u;
+      if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
+    }
+    if (i != st.n_sym - 1) {
+      const uint64_t span = (uint64_t)hl + 1;
+      high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
+      low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
+      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
+      low <<= n;
+      high = (high << n) | ((1u << n) - 1u);
+      value = (uint32_t)(((uint64_t)value << n)) | src.take(n);
+      const uint32_t y = (low & ~high) << 1;
+      const uint32_t m3 = (uint32_t)__builtin_clz(~y);
+      if (m3 > 0) {
+        low = (low << m3) & 0x7FFFFFFFu;
+        high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
+        value = ((value << m3) ^ 0x80000000u) | src.take(m3);
+      }
+    }
+  };
+
+  // two register buffers, used alternately: while one group is decoded the next one is in flight
+  RowRegs bufA[DEC_G], bufB[DEC_G];
 #pragma unroll
-    for (int g = 0; g < DEC_G; ++g) cur[g] = nxt[g];
+  for (int g = 0; g < DEC_G; ++g) fetch(bufA[g], (uint32_t)g < st.n_sym);
+  for (uint32_t base = 0; base < st.n_sym; base += 2 * DEC_G) {
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g) fetch(bufB[g], base + DEC_G + g < st.n_sym);
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g)
+      if (base + g < st.n_sym) decode_one(bufA[g], base + g);
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g) fetch(bufA[g], base + 2 * DEC_G + g < st.n_sym);
+#pragma unroll
+    for (int g = 0; g < DEC_G; ++g)
+      if (base + DEC_G + g < st.n_sym) decode_one(bufB[g], base + DEC_G + g);
   }
 }
 

@@ -40,45 +40,84 @@ def split_sections(frame_bytes):
     return out
 
 
-def finalize_frames(frames_sections):
+class EntropyJob:
+    """Range-encode launches of a set of frames, possibly still running on a side stream."""
+
+    def __init__(self, n_frames, present, heads, jobs, out_h, lens_h, offs, event, keep):
+        self.n_frames, self.present, self.heads, self.jobs = n_frames, present, heads, jobs
+        self.out_h, self.lens_h, self.offs, self.event, self.keep = out_h, lens_h, offs, event, keep
+
+    def collect(self):
+        """-> list of frame byte strings (waits for the side stream)."""
+        payload = [[b''] * 4 for _ in range(self.n_frames)]
+        if self.jobs:
+            self.event.synchronize()
+            out_h, lens_h = self.out_h.numpy(), self.lens_h.numpy()
+            for (fi, si), (off, _cap), ln in zip(self.jobs, self.offs, lens_h):
+                if int(ln) < 0:
+                    raise RuntimeError('range encoder output buffer overflow')
+                payload[fi][si] = out_h[off:off + int(ln)].tobytes()
+        frames = []
+        for fi in range(self.n_frames):
+            blob = b''
+            for si in range(4):
+                if not self.present[fi][si]:
+                    blob += (0).to_bytes(4, 'big')
+                else:
+                    body = self.heads[fi][si] + payload[fi][si]
+                    blob += len(body).to_bytes(4, 'big') + body
+            frames.append(blob)
+        self.keep = None
+        return frames
+
+
+def launch_finalize(frames_sections, side_stream=None):
     """frames_sections: list (one entry per frame) of 4-lists of PendingSection / None.
-    One host sync for all non-zero-map flags, then the CDF-bound kernels and ONE batched
-    range-encode launch per 64 streams (a wavefront per stream, all concurrent), one D2H.
-    Returns the list of frame byte strings."""
+    One host sync for all non-zero-map flags (C bytes per latent), then the CDF-bound kernels and ONE
+    batched range-encode launch per 64 streams (a wavefront per stream, all concurrent) and an async
+    D2H -- on `side_stream` when given, so the transforms of the next frames overlap with it."""
     lap = [(fi, si, s) for fi, secs in enumerate(frames_sections) for si, s in enumerate(secs)
            if s is not None and s.mode == 'laplace']
     flags_h = torch.stack([s.flags for _, _, s in lap]).cpu().numpy() if lap else None  # the one sync
-    heads = [[None] * 4 for _ in frames_sections]
-    jobs = []
-    for j, (fi, si, s) in enumerate(lap):
-        maps = [int(c) for c in np.nonzero(flags_h[j])[0]]
-        heads[fi][si] = bytes([len(maps)]) + bytes(maps)
-        if maps:
-            jobs.append((fi, si, ops.laplace_bounds(s.sigma, s.q, maps)))
-    for fi, secs in enumerate(frames_sections):
-        for si, s in enumerate(secs):
-            if s is not None and s.mode == 'pmf':
-                heads[fi][si] = b''
-                jobs.append((fi, si, ops.table_bounds(s.table, s.q)))
-    payload = [[b''] * 4 for _ in frames_sections]
-    if jobs:
-        out, lens, offs = ops.range_encode([b for _, _, b in jobs])
-        out_h, lens_h = out.cpu().numpy(), lens.cpu().numpy()
-        for (fi, si, _), (off, _cap), ln in zip(jobs, offs, lens_h):
-            if int(ln) < 0:
-                raise RuntimeError('range encoder output buffer overflow')
-            payload[fi][si] = out_h[off:off + int(ln)].tobytes()
-    frames = []
-    for fi, secs in enumerate(frames_sections):
-        blob = b''
-        for si in range(4):
-            if secs[si] is None:
-                blob += (0).to_bytes(4, 'big')
-            else:
-                body = heads[fi][si] + payload[fi][si]
-                blob += len(body).to_bytes(4, 'big') + body
-        frames.append(blob)
-    return frames
+    present = [[s is not None for s in secs] for secs in frames_sections]
+    heads = [[b''] * 4 for _ in frames_sections]
+    main = torch.cuda.current_stream()
+    ctx = torch.cuda.stream(side_stream) if side_stream is not None else None
+    if ctx is not None:
+        side_stream.wait_stream(main)
+        ctx.__enter__()
+    try:
+        jobs, bounds = [], []
+        for j, (fi, si, s) in enumerate(lap):
+            maps = [int(c) for c in np.nonzero(flags_h[j])[0]]
+            heads[fi][si] = bytes([len(maps)]) + bytes(maps)
+            if maps:
+                jobs.append((fi, si))
+                bounds.append(ops.laplace_bounds(s.sigma, s.q, maps))
+        for fi, secs in enumerate(frames_sections):
+            for si, s in enumerate(secs):
+                if s is not None and s.mode == 'pmf':
+                    jobs.append((fi, si))
+                    bounds.append(ops.table_bounds(s.table, s.q))
+        out_h = lens_h = offs = event = None
+        keep = [frames_sections, bounds]
+        if jobs:
+            out, lens, offs = ops.range_encode(bounds)
+            out_h = torch.empty(out.shape, dtype=torch.uint8, pin_memory=True)
+            lens_h = torch.empty(lens.shape, dtype=torch.int32, pin_memory=True)
+            out_h.copy_(out, non_blocking=True)
+            lens_h.copy_(lens, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            keep += [out, lens]
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return EntropyJob(len(frames_sections), present, heads, jobs, out_h, lens_h, offs, event, keep)
+
+
+def finalize_frames(frames_sections):
+    return launch_finalize(frames_sections).collect()
 
 
 def finalize_frame(sections):

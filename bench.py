@@ -93,11 +93,13 @@ def cpu_baseline(width, height, model):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--gop', type=str, default='1_GOP_32')
+    ap.add_argument('--units', type=int, default=4, help='intra-period units per step per GPU (4 x 33 = the 128-frame clip of BASELINE configs[3])')
+    ap.add_argument('--max-batch', type=int, default=8)
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -124,11 +126,13 @@ def main():
     synth.calibrate_operating_point(model, dev)
     if world > 1:
         broadcast_model(model)  # the one collective: weights over RCCL/xGMI
-    fc = model.frame_codec()
+    from aivc_amd.codec import FrameCodec
+    fc = FrameCodec(model, max_batch=args.max_batch)
     unit = len(generate_gop_struct(args.gop))
+    per_step = unit * args.units
     n_total = args.warmup + args.steps + 1
     # unit u of this rank's share = global unit (rank + u * world)
-    clips = [gpu_synthetic_unit(args.width, args.height, unit, (rank + i * world) * unit, dev, 666 + rank + i * world)
+    clips = [gpu_synthetic_unit(args.width, args.height, per_step, (rank + i * world) * per_step, dev, 666 + rank + i * world)
              for i in range(n_total)]
     torch.cuda.synchronize()
 
@@ -208,19 +212,19 @@ def main():
         cpu = cpu_baseline(args.width, args.height, model)
 
     if rank == 0:
-        frames = world * args.steps * unit
+        frames = world * args.steps * per_step
         out = {
             'metric': 'encode+decode fps @1080p YUV420 (RA GOP32)',
             'value': round(frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: one %d-frame intra-period unit encoded + '
+            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: %d-frame clip (%d intra-period units of %d frames) encoded + '
                                    'decoded per step per GPU; synthetic random-init stand-in for model ms_ssim-4 '
-                                   '(widths %s); units sharded across GPUs' % (args.width, args.height, args.gop, unit, widths),
-                       'frames_per_step': unit, 'parallelism': 'unit-sharded x%d' % world},
-            'encode_fps_rank0': round(args.steps * unit / stats['enc_s'], 3),
-            'decode_fps_rank0': round(args.steps * unit / stats['dec_s'], 3),
-            'bytes_per_frame': round(stats['bytes'] / (args.steps * unit), 1),
+                                   '(widths %s); units sharded across GPUs' % (args.width, args.height, args.gop, per_step, args.units, unit, widths),
+                       'frames_per_step': per_step, 'units_per_step': args.units, 'parallelism': 'unit-sharded x%d' % world},
+            'encode_fps_rank0': round(args.steps * per_step / stats['enc_s'], 3),
+            'decode_fps_rank0': round(args.steps * per_step / stats['dec_s'], 3),
+            'bytes_per_frame': round(stats['bytes'] / (args.steps * per_step), 1),
             'closed_loop_ok': bool(closed_loop),
             'roofline': roofline, 'cpu_baseline': cpu,
         }
