@@ -34,7 +34,7 @@ constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int UA = BM * 4 / 256;          // (row, octet) units per thread for A
   constexpr int UB = (BN * 4 + 255) / 256;  // ... for B
@@ -268,14 +268,20 @@ static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   return check_launch("conv_mfma");
 }
 
-// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32
+// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128
 static int pick_tile(const aivc_conv_params &p) {
   const bool t = p.mode == AIVC_MODE_TCONV;
   const long M = t ? (long)p.n * p.h_in * p.w_in : (long)p.n * p.h_out * p.w_out;
   const int z = t ? 4 : 1;
   const int co = p.c_out;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((co + bn - 1) / bn) * z; };
-  if (co > 64) return blocks(128, 128) >= 384 ? 0 : 1;
+  if (co > 64) {
+    // 64x128 per wave (half the staging per FLOP) pays off when the reduction is long enough to
+    // amortise the bigger prologue/epilogue and there are >= 2 rounds of blocks
+    const int taps = t ? (p.ksize * p.ksize + 3) / 4 : p.ksize * p.ksize;
+    if (co % 128 == 0 && taps * p.c_in >= 1024 && blocks(256, 128) >= 1024) return 4;
+    return blocks(128, 128) >= 384 ? 0 : 1;
+  }
   if (co > 32) return blocks(256, 64) >= 384 ? 2 : 1;
   return 3;
 }
@@ -286,6 +292,7 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
     case 0: return launch_cfg<MODE, 2, 2, 2, 2>(p, s);
     case 1: return launch_cfg<MODE, 2, 2, 1, 1>(p, s);
     case 2: return launch_cfg<MODE, 4, 1, 2, 2>(p, s);
+    case 4: return launch_cfg<MODE, 4, 1, 2, 4>(p, s);
     default: return launch_cfg<MODE, 4, 1, 1, 1>(p, s);
   }
 }

@@ -26,16 +26,17 @@ SHAPES = [  # name, mode, k, s, pad, cin, cout, h_in, w_in
 
 def main():
     dev = torch.device('cuda:0')
+    nb = int(os.environ.get('BATCH', '1'))
     tot_f, tot_t = 0.0, 0.0
     for name, mode, k, s, pad, ci, co, h, w in SHAPES:
-        x = torch.randn(1, h, w, ci, device=dev)
+        x = torch.randn(nb, h, w, ci, device=dev)
         wt = torch.randn(co, k, k, ci, device=dev) * 0.05
         b = torch.rand(co, device=dev) + 0.5
         if mode in (abi.MODE_GDN, abi.MODE_IGDN):
             wt = wt.abs()
         ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
         taps = k * k if mode != abi.MODE_TCONV else k * k / 4.0
-        flops = 2.0 * taps * ci * co * ho * wo
+        flops = 2.0 * taps * ci * co * ho * wo * nb
         for algo in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_DIRECT, abi.ALGO_MFMA]):
             for _ in range(2):
                 ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Run ONE conv shape a few times (for rocprofv3 --pmc passes).  usage: conv_probe.py <shape-index> [reps]"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from aivc_amd import abi, ops
+from bench_conv import SHAPES
+
+PROBES = SHAPES + [('conv3 128 @270p (38 GF)', abi.MODE_CONV, 3, 1, 1, 128, 128, 270, 480)]
+
+
+def main():
+    idx = int(sys.argv[1]) if len(sys.argv) > 1 else len(PROBES) - 1
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    name, mode, k, s, pad, ci, co, h, w = PROBES[idx]
+    dev = torch.device('cuda:0')
+    x = torch.randn(1, h, w, ci, device=dev)
+    wt = torch.randn(co, k, k, ci, device=dev) * 0.05
+    b = torch.rand(co, device=dev) + 0.5
+    if mode in (abi.MODE_GDN, abi.MODE_IGDN):
+        wt = wt.abs()
+    for _ in range(reps):
+        ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad)
+    torch.cuda.synchronize()
+    print('probe', name)
+
+
+if __name__ == '__main__':
+    main()
