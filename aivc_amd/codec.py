@@ -32,8 +32,9 @@ class FrameCodec:
     """max_batch bounds how many frames of one dependency level are pushed through the transforms
     together (activations of a 1080p frame at 1/2 resolution are 133 MB per 64-channel tensor)."""
 
-    def __init__(self, full_net, max_batch=8):
+    def __init__(self, full_net, max_batch=8, entropy_chunk=64):
         self.net = full_net
+        self.entropy_chunk = entropy_chunk
         self.mof = full_net.mode_net.mode_net
         self.cod = full_net.codec_net.codec_net
         self.max_batch = max_batch
@@ -85,34 +86,45 @@ class FrameCodec:
             res['aux'] = out['aux']
         return res
 
-    def _decode_net(self, net, pay_z, pay_y, frame_type, data_dim, in_shortcut, idx_rate, device):
+    def entropy_decode(self, frames_bytes, frame_type, data_dim, idx_rate=0., device=None):
+        """Entropy stage of the decoder for n frames of one type: z streams -> h_s -> (mu, sigma) ->
+        y streams -> y_hat.  It depends on the bitstream only (never on reconstructed frames), so the
+        caller may run it for every frame of a video up front, all streams concurrently.
+        -> {'mof': y_hat [n,h_y,w_y,C] or None, 'cod': y_hat}"""
+        device = device or torch.device('cuda')
+        secs = [split_sections(b) for b in frames_bytes]
         h_y, w_y = data_dim['y']
         h_z, w_z = data_dim['z']
-        q_z = net.ac.decode_z(pay_z, h_z, w_z, net.nb_ft_z, device)
-        y_hat = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(pay_y, sigma), frame_type,
-                                         (h_y, w_y), idx_rate)
-        return net.synthesise(y_hat, in_shortcut)
+        out = {'mof': None}
+        for name, net, iz, iy in (('mof', self.mof, 0, 1), ('cod', self.cod, 2, 3)):
+            if name == 'mof' and frame_type == FRAME_I:
+                continue
+            q_z = net.ac.decode_z([s[iz] for s in secs], h_z, w_z, net.nb_ft_z, device)
+            pay_y = [s[iy] for s in secs]
+            out[name] = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(pay_y, sigma), frame_type,
+                                                 (h_y, w_y), idx_rate)
+        return out
 
-    def decode_batch(self, frames_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
-        """Mirror of Decoder.decode (src/real_life/decode.py:455-580) for n frames of one type.
-        -> list of uint8 plane dicts."""
-        device = device or torch.device('cuda')
-        n = len(frames_bytes)
+    def synthesise_batch(self, y_hats, prev, nxt, frame_type, data_dim):
+        """Reconstruction stage (mirror of Decoder.decode, src/real_life/decode.py:455-580) for n frames
+        of one type whose latents are already decoded.  -> list of uint8 plane dicts."""
         h, w = data_dim['x']
-        secs = [split_sections(b) for b in frames_bytes]
+        n = y_hats['cod'].shape[0]
         pred = skip = None
         if frame_type != FRAME_I:
             prev444 = self.to444(_stack(prev))
             next444 = self.to444(_stack(nxt)) if frame_type == FRAME_B else torch.zeros_like(prev444)
             short_in = torch.cat((prev444, next444), dim=3) if frame_type == FRAME_B else None
-            mof_out = self._decode_net(self.mof, [s[0] for s in secs], [s[1] for s in secs], frame_type, data_dim,
-                                       short_in, idx_rate, device)
+            mof_out = self.mof.synthesise(y_hats['mof'], short_in)
             wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3)
             pred, skip = wb['pred'], wb['skip']
-        cod_out = self._decode_net(self.cod, [s[2] for s in secs], [s[3] for s in secs], frame_type, data_dim, pred,
-                                   idx_rate, device)
+        cod_out = self.cod.synthesise(y_hats['cod'], pred)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         return _unstack(dict(zip('yuv', rec8)), n)
+
+    def decode_batch(self, frames_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
+        y_hats = self.entropy_decode(frames_bytes, frame_type, data_dim, idx_rate, device)
+        return self.synthesise_batch(y_hats, prev, nxt, frame_type, data_dim)
 
     def decode_frame(self, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
         return self.decode_batch([frame_bytes], [prev], [nxt], frame_type, data_dim, idx_rate, device)[0]
@@ -167,7 +179,10 @@ class FrameCodec:
         return blobs, [[rec[u][f] for f in names] for u in range(len(units))], data_dim
 
     def decode_units(self, gop_blobs, data_dim, device=None):
-        """-> [reconstructions (display order) per unit]"""
+        """-> [reconstructions (display order) per unit].
+        Stage 1 entropy-decodes EVERY frame of every unit (entropy_chunk frames at a time: that many
+        range-coder streams run concurrently, one wavefront each; the serial coder is off the
+        frame-to-frame critical path).  Stage 2 reconstructs level by level in batches."""
         parsed = [container.unpack_gop(g) for g in gop_blobs]
         out = [None] * len(gop_blobs)
         groups = {}
@@ -176,15 +191,25 @@ class FrameCodec:
         for (gop_name, idx_rate), members in groups.items():
             gop = generate_gop_struct(gop_name)
             names = sorted(gop, key=frame_index)
+            lat = {}
+            for ftype in (FRAME_I, FRAME_P, FRAME_B):
+                items = [(i, f) for i in members for f in names if gop[f]['type'] == ftype]
+                for s0 in range(0, len(items), self.entropy_chunk):
+                    chunk = items[s0:s0 + self.entropy_chunk]
+                    yh = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype, data_dim,
+                                             idx_rate, device)
+                    for j, it in enumerate(chunk):
+                        lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
             rec = {i: {} for i in members}
             for level in coding_levels(gop):
                 for ftype, chunk in self._chunks(gop, level, members):
-                    dec = self.decode_batch([parsed[i][2][frame_index(f)] for i, f in chunk],
-                                            [rec[i].get(gop[f]['prev_ref']) for i, f in chunk],
-                                            [rec[i].get(gop[f]['next_ref']) for i, f in chunk], ftype, data_dim,
-                                            idx_rate, device)
+                    yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
+                          for k in ('mof', 'cod')}
+                    dec = self.synthesise_batch(yh, [rec[i].get(gop[f]['prev_ref']) for i, f in chunk],
+                                                [rec[i].get(gop[f]['next_ref']) for i, f in chunk], ftype, data_dim)
                     for (i, f), r in zip(chunk, dec):
                         rec[i][f] = r
+                        del lat[(i, f)]
             for i in members:
                 out[i] = [rec[i][f] for f in names]
         return out
