@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 AIVC_OK = 0
 ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
@@ -32,8 +32,10 @@ class ConvParams(C.Structure):
     _fields_ = [('mode', C.c_int32), ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('n', C.c_int32), ('h_in', C.c_int32), ('w_in', C.c_int32), ('c_in', C.c_int32),
                 ('h_out', C.c_int32), ('w_out', C.c_int32), ('c_out', C.c_int32),
-                ('act1', C.c_int32), ('act2', C.c_int32), ('algo', C.c_int32),
-                ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f)]
+                ('act1', C.c_int32), ('act2', C.c_int32), ('algo', C.c_int32), ('gdn', C.c_int32),
+                ('reserved', C.c_int32),
+                ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
+                ('gdn_beta', _f), ('gdn_gamma', _f)]
 
 
 class MapList(C.Structure):

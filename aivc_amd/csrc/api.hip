@@ -19,7 +19,7 @@ int check_launch(const char *what) {
 }
 }  // namespace aivc
 
-AIVC_EXPORT int aivc_abi_version(void) { return 1; }
+AIVC_EXPORT int aivc_abi_version(void) { return 2; }
 AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
 
 static int validate_conv(const aivc_conv_params *p) {
@@ -45,12 +45,17 @@ static int validate_conv(const aivc_conv_params *p) {
     default:
       return AIVC_ERR_UNSUPPORTED;
   }
+  if (p->gdn) {
+    if (p->gdn < 0 || p->gdn > 2 || p->mode == AIVC_MODE_GDN || p->mode == AIVC_MODE_IGDN) return AIVC_ERR_ARG;
+    if (!p->gdn_beta || !p->gdn_gamma) return AIVC_ERR_ARG;
+  }
   return AIVC_OK;
 }
 
 AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
+  if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
   if (p->algo == AIVC_ALGO_DIRECT) return 0;
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
   return 0;
@@ -60,6 +65,10 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   hipStream_t s = aivc::to_stream(stream);
+  if (p->gdn) {  // fused (I)GDN exists on the MFMA path only
+    if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p)) return AIVC_ERR_UNSUPPORTED;
+    return aivc::conv2d_mfma(*p, s);
+  }
   if (p->algo == AIVC_ALGO_DIRECT) return aivc::conv2d_direct(*p, s);
   if (p->algo == AIVC_ALGO_MFMA) return aivc::conv2d_mfma(*p, s);
   if (aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma(*p, s);

@@ -38,6 +38,10 @@ struct Epilogue {
       const float nrm = __builtin_sqrtf(v);
       v = (mode == AIVC_MODE_IGDN) ? xc * nrm : xc / nrm;
     }
+    finish(opix, co, c_out, v);
+  }
+  // everything after the (I)GDN step
+  __device__ __forceinline__ void finish(size_t opix, int co, int c_out, float v) const {
     v = act_apply(act1, v);
     const size_t o = opix * c_out + co;
     if (mul) v = mul[o] * v;

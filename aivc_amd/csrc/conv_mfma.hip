@@ -33,7 +33,7 @@ struct MfmaArgs {
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
 __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int UA = BM * 4 / 256;          // (row, octet) units per thread for A
@@ -232,6 +232,77 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     }
   }
 
+  // ---- fused (I)GDN: second, small GEMM  s[m][i] = sum_j x[m][j]^2 * gamma[i][j]  -------------
+  // The biased conv outputs x stay in `acc`; their squares go through LDS (the A tile buffer) one
+  // 32-channel chunk at a time, gamma streams through the B tile buffer.  BN == c_out here, so a
+  // workgroup owns every channel of its pixels.
+  floatx16 acc2[FUSE ? TM : 1][FUSE ? TN : 1];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = (wn * TN + j) * 32 + (lane & 31);
+      const float b = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (p.bias) acc[i][j][r] = acc[i][j][r] + b;
+          acc2[i][j][r] = 0.0f;
+        }
+    }
+    const int k_in = lane & 31;
+    const int pos = (k_in >> 3) * 8 + (k_in & 1) * 4 + ((k_in & 7) >> 1);  // even ks first inside an octet
+    for (int kt2 = 0; kt2 < Cout / BK; ++kt2) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (wn * TN + j == kt2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const float xv = acc[i][j][r];
+              As[row * LDS_STRIDE + pos] = xv * xv;
+            }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = tid + 256 * j;
+        if (u < BN * 4) {
+          const float *src = p.gdn_gamma + (size_t)(u >> 2) * Cout + kt2 * BK + (u & 3) * 8;
+          const float4 q0 = *reinterpret_cast<const float4 *>(src);
+          const float4 q1 = *reinterpret_cast<const float4 *>(src + 4);
+          float *dst = Bs + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
+          *reinterpret_cast<float4 *>(dst) = make_float4(q0.x, q0.z, q1.x, q1.z);
+          *reinterpret_cast<float4 *>(dst + 4) = make_float4(q0.y, q0.w, q1.y, q1.w);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + j * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = s == 0 ? af[i].x : (s == 1 ? af[i].y : (s == 2 ? af[i].z : af[i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
   // ---- epilogue ---------------------------------------------------------------------------
   Epilogue ep{p.bias, p.mul, p.res, p.x, p.y, p.act1, p.act2, p.mode};
 #pragma unroll
@@ -249,13 +320,19 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (co < Cout) ep.store(opix, co, Cout, acc[i][j][r]);
+        if constexpr (FUSE) {
+          const float nrm = __builtin_sqrtf(acc2[i][j][r] + p.gdn_beta[co]);
+          const float xv = acc[i][j][r];
+          ep.finish(opix, co, Cout, p.gdn == 2 ? xv * nrm : xv / nrm);
+        } else {
+          if (co < Cout) ep.store(opix, co, Cout, acc[i][j][r]);
+        }
       }
     }
   }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
 static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   MfmaArgs a;
@@ -264,7 +341,7 @@ static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   a.cin_magic = (uint32_t)((0x100000000ull + (uint64_t)p.c_in - 1) / (uint64_t)p.c_in);
   dim3 grid((a.M + BM - 1) / BM, (p.c_out + BN - 1) / BN, MODE == AIVC_MODE_TCONV ? 4 : 1);
   const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
@@ -275,6 +352,11 @@ static int pick_tile(const aivc_conv_params &p) {
   const int z = t ? 4 : 1;
   const int co = p.c_out;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((co + bn - 1) / bn) * z; };
+  if (p.gdn) {  // fused (I)GDN: the tile must span all output channels (BN == c_out)
+    if (co == 128) return 0;
+    if (co == 64) return blocks(256, 64) >= 384 ? 2 : 1;
+    return 3;  // co == 32
+  }
   if (co > 64) {
     // 64x128 per wave (half the staging per FLOP) pays off when the reduction is long enough to
     // amortise the bigger prologue/epilogue and there are >= 2 rounds of blocks
@@ -288,21 +370,33 @@ static int pick_tile(const aivc_conv_params &p) {
 
 template <int MODE>
 static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
-  switch (pick_tile(p)) {
-    case 0: return launch_cfg<MODE, 2, 2, 2, 2>(p, s);
-    case 1: return launch_cfg<MODE, 2, 2, 1, 1>(p, s);
-    case 2: return launch_cfg<MODE, 4, 1, 2, 2>(p, s);
-    case 4: return launch_cfg<MODE, 4, 1, 2, 4>(p, s);
-    default: return launch_cfg<MODE, 4, 1, 1, 1>(p, s);
+  const int tile = pick_tile(p);
+  if constexpr (MODE != AIVC_MODE_GDN) {
+    if (p.gdn) {
+      switch (tile) {
+        case 0: return launch_cfg<MODE, 2, 2, 2, 2, true>(p, s);
+        case 1: return launch_cfg<MODE, 2, 2, 1, 1, true>(p, s);
+        case 2: return launch_cfg<MODE, 4, 1, 2, 2, true>(p, s);
+        default: return launch_cfg<MODE, 4, 1, 1, 1, true>(p, s);
+      }
+    }
+  }
+  switch (tile) {
+    case 0: return launch_cfg<MODE, 2, 2, 2, 2, false>(p, s);
+    case 1: return launch_cfg<MODE, 2, 2, 1, 1, false>(p, s);
+    case 2: return launch_cfg<MODE, 4, 1, 2, 2, false>(p, s);
+    case 4: return launch_cfg<MODE, 4, 1, 2, 4, false>(p, s);
+    default: return launch_cfg<MODE, 4, 1, 1, 1, false>(p, s);
   }
 }
 
 int conv2d_mfma_variant(const aivc_conv_params &p) {
   const int mode = p.mode == AIVC_MODE_TCONV ? 1 : (p.mode == AIVC_MODE_CONV ? 0 : 2);
-  return 100 + 10 * mode + pick_tile(p);
+  return 100 + 10 * mode + pick_tile(p) + (p.gdn ? 50 : 0);
 }
 
 bool conv2d_mfma_supported(const aivc_conv_params &p) {
+  if (p.gdn && p.c_out != 32 && p.c_out != 64 && p.c_out != 128) return false;
   // thin outputs (c_out of 3 / 6): N is padded to 32, still ~6x faster than the scalar kernel once
   // the reduction is long; tiny reductions stay scalar
   if (p.c_out < 16 && p.c_in * p.ksize * p.ksize < 256) return false;

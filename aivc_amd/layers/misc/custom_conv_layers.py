@@ -48,18 +48,25 @@ def packed_conv(conv, c_store, device):
     return cached(conv, ('w', c_store, str(device)), params, build)
 
 
-def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=None):
-    """x NHWC -> NHWC through one aivc_conv2d launch for a torch Conv2d / ConvTranspose2d."""
+def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=None, gdn=None):
+    """x NHWC -> NHWC through one aivc_conv2d launch for a torch Conv2d / ConvTranspose2d.
+    gdn: optional GDN module applied to the conv output (fused into the epilogue when possible)."""
     c_store = (x.shape[-1] + 3) // 4 * 4
     w, b = packed_conv(conv, c_store, x.device)
+    g = None
+    if gdn is not None:
+        if gdn.beta.shape[0] % 4:  # exotic channel count: padded stand-alone path
+            return gdn.forward_nhwc(run_conv(conv, x, pad), res=res)
+        be, ge = gdn.effective_params(x.device)
+        g = (be, ge, bool(gdn.inverse))
     if isinstance(conv, ConvTranspose2d):
         k = _sq(conv.kernel_size)
         if _sq(conv.stride) != 2 or _sq(conv.output_padding) != 1 or _sq(conv.padding) != (k + 1) // 2 - 1:
             raise NotImplementedError('only the reference UpscalingLayer geometry is implemented')
-        return ops.conv2d(x, w, b, mode=abi.MODE_TCONV, stride=2, act1=act1, act2=act2, res=res, mul=mul)
+        return ops.conv2d(x, w, b, mode=abi.MODE_TCONV, stride=2, act1=act1, act2=act2, res=res, mul=mul, gdn=g)
     if _sq(conv.padding) != 0 or _sq(conv.dilation) != 1 or conv.groups != 1:
         raise NotImplementedError('Conv2d with built-in padding/dilation/groups is not used by the codec')
-    return ops.conv2d(x, w, b, stride=_sq(conv.stride), pad=pad, act1=act1, act2=act2, res=res, mul=mul)
+    return ops.conv2d(x, w, b, stride=_sq(conv.stride), pad=pad, act1=act1, act2=act2, res=res, mul=mul, gdn=g)
 
 
 def _split_nl(seq):
@@ -85,7 +92,7 @@ class CustomConvLayer(nn.Module):
         pad = _sq(pad_mod.padding)
         nl = _split_nl(self.layers)
         if isinstance(nl, GDN):
-            return nl.forward_nhwc(run_conv(conv, x, pad), res=res)
+            return run_conv(conv, x, pad, res=res, gdn=nl)
         return run_conv(conv, x, pad, act1=_act_of(nl), res=res)
 
     def forward(self, x):
@@ -109,7 +116,7 @@ class UpscalingLayer(nn.Module):
     def forward_nhwc(self, x, res=None):
         nl = _split_nl(self.layers)
         if isinstance(nl, GDN):
-            return nl.forward_nhwc(run_conv(self.layers[0], x, 0), res=res)
+            return run_conv(self.layers[0], x, 0, res=res, gdn=nl)
         return run_conv(self.layers[0], x, 0, act1=_act_of(nl), res=res)
 
     def forward(self, x):

@@ -76,8 +76,11 @@ def pack_weight(w, c_store=None, transposed=False):
 
 
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
-           res=None, algo=abi.ALGO_AUTO):
-    """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h)."""
+           res=None, algo=abi.ALGO_AUTO, gdn=None):
+    """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h).
+    gdn = (beta_eff, gamma_eff, inverse) fuses the (inverse) GDN into the conv epilogue when the
+    kernels can (all channels of a pixel in one tile), else it is issued as a second launch --
+    bit-identical either way."""
     x = _dev(x, torch.float32, 'x')
     n, h, w_, c = x.shape
     c_real = c
@@ -96,8 +99,18 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     for t, nm in ((mul, 'mul'), (res, 'res')):
         if t is not None and tuple(t.shape) != tuple(y.shape):
             raise AivcNativeError('conv2d: %s shape %s != output shape %s' % (nm, tuple(t.shape), tuple(y.shape)))
-    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo,
-                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y))
+    if gdn is not None:
+        g_beta, g_gamma, g_inv = gdn
+        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 2 if g_inv else 1, 0,
+                           _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(g_beta), _p(g_gamma))
+        from ._lib import load
+        if load()['aivc_conv2d_variant'](C.byref(p)) < 0:  # not fusable for this shape: two launches
+            t = conv2d(x, w_ohwi, bias, mode=mode, stride=stride, pad=pad, algo=algo)
+            return globals()['gdn'](t, g_beta, g_gamma, inverse=g_inv, res=res, algo=algo) if act1 == 0 and \
+                act2 == 0 and mul is None else _unsupported_gdn_epilogue()
+    else:
+        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, 0,
+                           _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), None, None)
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
         return y
@@ -106,13 +119,17 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     variant = load()['aivc_conv2d_variant'](C.byref(p))
     taps = k * k
     pix = n * h * w_ if mode == abi.MODE_TCONV else n * ho * wo
-    flops = 2.0 * taps * c_real * co * pix
+    flops = 2.0 * taps * c_real * co * pix + (2.0 * co * co * n * ho * wo if gdn is not None else 0.0)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call('aivc_conv2d', C.byref(p), _stream())
     e1.record()
     PROFILE.append((variant, flops, e0, e1))
     return y
+
+
+def _unsupported_gdn_epilogue():
+    raise AivcNativeError('conv2d: fused gdn with act/mul epilogue needs a fusable shape')
 
 
 def gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):

@@ -188,6 +188,9 @@ def main():
             d[1] += flops
             d[2] += e0.elapsed_time(e1) * 1e-3
         ops.PROFILE = None
+        for v in list(per):
+            if v >= 150 and (v - 50) in VARIANT_NAMES and v not in VARIANT_NAMES:
+                VARIANT_NAMES[v] = VARIANT_NAMES[v - 50].replace('>', '+gdn>')
         mf = {v: d for v, d in per.items() if v >= 100}
         if mf:
             dom = max(mf, key=lambda v: mf[v][2])

@@ -53,7 +53,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void);
+int aivc_abi_version(void); /* currently 2 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -87,15 +87,26 @@ typedef struct aivc_conv_params {
   int32_t act1;                /* applied to acc + bias                */
   int32_t act2;                /* applied after the residual addition   */
   int32_t algo;                /* AIVC_ALGO_* (AUTO picks MFMA when the shape allows) */
+  int32_t gdn;                 /* CONV/TCONV only: 0 none, 1 GDN, 2 inverse GDN fused after the bias */
+  int32_t reserved;
   const float *x;    /* [n][h_in][w_in][c_in] */
   const float *w;    /* [c_out][ksize][ksize][c_in]  (OHWI; TCONV: w[co][ky][kx][ci] = torch weight[ci][co][ky][kx]) */
   const float *bias; /* [c_out] or NULL */
   const float *mul;  /* [n][h_out][w_out][c_out] or NULL: v = mul * v (after act1) */
   const float *res;  /* [n][h_out][w_out][c_out] or NULL: v = v + res (after mul)  */
   float *y;          /* [n][h_out][w_out][c_out] */
+  const float *gdn_beta;  /* [c_out]         effective (re-parameterised) beta,  when gdn != 0 */
+  const float *gdn_gamma; /* [c_out][c_out]  effective gamma [i][j],             when gdn != 0 */
 } aivc_conv_params;
-/* Epilogue order:  v = acc + bias;  [GDN: v = x / sqrtf(v) | IGDN: v = x * sqrtf(v)];
- *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v). */
+/* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
+ *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
+ *                     s_i = fmaf chain over j ascending of (t_j, gamma[i][j]) from +0, then + beta[i];
+ *                     v_i = gdn == 1 ? v_i / sqrtf(s_i) : v_i * sqrtf(s_i)
+ *                   -- bit identical to a CONV launch followed by a GDN/IGDN-mode launch];
+ *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v).
+ * A fused-gdn request the kernels cannot honour (all output channels of a pixel must sit in one
+ * workgroup tile: c_out of 64 or 128 on the MFMA path) returns AIVC_ERR_UNSUPPORTED; callers then
+ * issue the two launches (aivc_conv2d_variant tells in advance). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
 /* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,

@@ -91,7 +91,8 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
 
 
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
-           res=None):
+           res=None, gdn=None):
+    """gdn = (beta_eff, gamma_eff, inverse): (inverse) GDN fused after the bias"""
     x = _f32(x)
     n, h, w_, c = x.shape
     if c % 4:
@@ -107,8 +108,12 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     bias = None if bias is None else _f32(bias)
     mul = None if mul is None else _f32(mul)
     res = None if res is None else _f32(res)
-    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0,
-                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y))
+    gb = gg = None
+    gflag = 0
+    if gdn is not None:
+        gb, gg, gflag = _f32(gdn[0]), _f32(gdn[1]), (2 if gdn[2] else 1)
+    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0, gflag, 0,
+                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg))
     _chk(lib()['aivc_conv2d'](C.byref(p), None), 'aivc_conv2d')
     return y
 

@@ -238,3 +238,34 @@ def test_range_coder_many_streams_concurrently(oracle, cuda):
     dec = ops.range_decode(pl, rows, offs, ns, [0] * 70)
     for i in range(70):
         eq(dec[i], want[i])
+
+
+@pytest.mark.parametrize('case', [
+    # mode, k, stride, pad, cin, cout, h, w, inverse, res
+    (abi.MODE_CONV, 5, 2, 2, 12, 64, 31, 45, False, False),
+    (abi.MODE_CONV, 5, 2, 2, 64, 128, 33, 29, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 128, 128, 17, 19, False, True),
+    (abi.MODE_CONV, 3, 1, 1, 128, 128, 17, 19, True, True),
+    (abi.MODE_TCONV, 5, 2, 0, 128, 128, 9, 11, True, False),
+    (abi.MODE_TCONV, 5, 2, 0, 128, 64, 23, 21, True, False),
+    (abi.MODE_CONV, 3, 1, 1, 32, 32, 9, 9, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 8, 8, 9, 9, False, True),      # not fusable: two launches
+])
+def test_fused_gdn_bit_exact(case, oracle, cuda):
+    """conv + (I)GDN fused in one launch == oracle fused == oracle conv followed by oracle GDN"""
+    from aivc_amd import ops
+    mode, k, s, pad, ci, co, h, w, inv, use_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((2, h, w, ci), dtype=np.float32)
+    wt = (rng.standard_normal((co, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)
+    bias = rng.standard_normal(co, dtype=np.float32)
+    beta = (np.abs(rng.standard_normal(co)) + 0.2).astype(np.float32)
+    gamma = (np.abs(rng.standard_normal((co, co))) * 0.05).astype(np.float32)
+    ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+    res = rng.standard_normal((2, ho, wo, co), dtype=np.float32) if use_res else None
+    two = oracle.gdn(oracle.conv2d(x, wt, bias, mode=mode, stride=s, pad=pad), beta, gamma, inverse=inv, res=res)
+    fused = oracle.conv2d(x, wt, bias, mode=mode, stride=s, pad=pad, res=res, gdn=(beta, gamma, inv))
+    np.testing.assert_array_equal(fused, two)
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(bias, cuda), mode=mode, stride=s, pad=pad,
+                     res=None if res is None else T(res, cuda), gdn=(T(beta, cuda), T(gamma, cuda), inv))
+    eq(got, two)

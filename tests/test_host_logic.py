@@ -46,14 +46,14 @@ def test_argument_validation_without_gpu():
     from aivc_amd import _lib, abi
     fns = _lib.load()
     assert fns['aivc_conv2d'](None, None) == -1
-    p = abi.ConvParams(abi.MODE_CONV, 7, 1, 3, 1, 8, 8, 4, 8, 8, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    p = abi.ConvParams(abi.MODE_CONV, 7, 1, 3, 1, 8, 8, 4, 8, 8, 4, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None)
     assert fns['aivc_conv2d'](ctypes.byref(p), None) == -2  # ksize 7 unsupported
-    p = abi.ConvParams(abi.MODE_CONV, 3, 1, 1, 1, 8, 8, 3, 8, 8, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    p = abi.ConvParams(abi.MODE_CONV, 3, 1, 1, 1, 8, 8, 3, 8, 8, 4, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None)
     assert fns['aivc_conv2d'](ctypes.byref(p), None) == -1  # c_in not a multiple of 4
-    p = abi.ConvParams(abi.MODE_CONV, 3, 2, 1, 1, 9, 9, 4, 4, 5, 4, 0, 0, 0, 1, 1, None, None, None, 1)
+    p = abi.ConvParams(abi.MODE_CONV, 3, 2, 1, 1, 9, 9, 4, 4, 5, 4, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None)
     assert fns['aivc_conv2d'](ctypes.byref(p), None) == -1  # wrong output size
     assert fns['aivc_conv2d_variant'](ctypes.byref(abi.ConvParams(
-        abi.MODE_CONV, 3, 1, 1, 1, 270, 480, 128, 270, 480, 128, 0, 0, 0, 1, 1, None, None, None, 1))) == 100
+        abi.MODE_CONV, 3, 1, 1, 1, 270, 480, 128, 270, 480, 128, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None))) == 100
 
 
 def test_product_path_refuses_cpu_tensors():
