@@ -55,5 +55,7 @@ int conv2d_direct(const aivc_conv_params &p, hipStream_t s);
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s);  // AIVC_ERR_UNSUPPORTED if shape not covered
 bool conv2d_mfma_supported(const aivc_conv_params &p);
 int conv2d_mfma_variant(const aivc_conv_params &p);  // 100 + 10*mode + tile id
+bool conv2d_thin_supported(const aivc_conv_params &p);
+int conv2d_thin(const aivc_conv_params &p, hipStream_t s);  // VALU kernel for c_out of 3 / 6 (transposed conv)
 
 }  // namespace aivc

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
-VARIANT_NAMES = {0: 'conv_direct_kernel', 100: 'conv_mfma<conv,128x128>', 101: 'conv_mfma<conv,64x64>',
+VARIANT_NAMES = {0: 'conv_direct_kernel', 1: 'thin_tconv_kernel', 100: 'conv_mfma<conv,128x128>', 101: 'conv_mfma<conv,64x64>',
                  102: 'conv_mfma<conv,256x64>', 103: 'conv_mfma<conv,128x32>', 104: 'conv_mfma<conv,256x128>', 114: 'conv_mfma<tconv,256x128>', 124: 'conv_mfma<gdn,256x128>', 110: 'conv_mfma<tconv,128x128>',
                  111: 'conv_mfma<tconv,64x64>', 112: 'conv_mfma<tconv,256x64>', 113: 'conv_mfma<tconv,128x32>',
                  120: 'conv_mfma<gdn,128x128>', 121: 'conv_mfma<gdn,64x64>', 122: 'conv_mfma<gdn,256x64>',

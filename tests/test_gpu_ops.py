@@ -50,6 +50,10 @@ CONV_CASES = [
     (abi.MODE_IGDN, 1, 1, 0, 64, 64, 33, 31, 0, 0, False, True),
     (abi.MODE_CONV, 3, 1, 1, 128, 192, 9, 11, 0, 0, False, False),
     (abi.MODE_CONV, 3, 1, 1, 64, 256, 20, 20, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 64, 6, 37, 41, 0, 0, False, False),
+    (abi.MODE_TCONV, 3, 2, 0, 64, 3, 17, 33, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_TCONV, 5, 2, 0, 128, 3, 9, 19, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 16, 6, 16, 16, 0, abi.ACT_RELU, False, True),
 ]
 
 

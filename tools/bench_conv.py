@@ -37,7 +37,7 @@ def main():
         ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
         taps = k * k if mode != abi.MODE_TCONV else k * k / 4.0
         flops = 2.0 * taps * ci * co * ho * wo * nb
-        for algo in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_DIRECT, abi.ALGO_MFMA]):
+        for algo in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_MFMA, abi.ALGO_AUTO]):
             for _ in range(2):
                 ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)
             torch.cuda.synchronize()
