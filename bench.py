@@ -197,9 +197,18 @@ def main():
             cnt, fl, sec = mf[dom]
             all_fl = sum(d[1] for d in mf.values())
             all_sec = sum(d[2] for d in mf.values())
+            traffic, traffic_note = None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_probe.json')
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
+                    traffic = pj['traffic_bytes_per_launch']
+                    traffic_note = ('HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on '
+                                    'the probe shape (%s): %d B vs %d B algorithmic' % (pj['probe'], traffic,
+                                                                                         pj['algorithmic_bytes_per_launch']))
             roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
                         'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                        'frac': round(fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_note': traffic_note,
                         'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 2),
                         'gflop_per_launch': round(fl / cnt / 1e9, 3),
                         'all_mfma_conv': {'achieved': round(all_fl / all_sec / 1e12, 2),

@@ -71,3 +71,87 @@ def test_default_width_model_closed_loop(cuda):
     for i, (d, e) in enumerate(zip(dec, rec)):
         for k in 'yuv':
             assert torch.equal(d[k], e[k]), (i, k)
+
+
+# ---- BASELINE.json configurations at full frame size: size-independent properties ------------------
+def _closed_loop(cuda, w, h, n, gop, model=None, max_batch=8):
+    from aivc_amd import synth
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.models import arch
+    from aivc_amd.real_life import cat_binary_files as cont
+    if model is None:
+        model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+        synth.calibrate_operating_point(model, cuda)
+    frames = synth.to_device_frames(synth.synthetic_video(w, h, n, seed=9), cuda)
+    fc = FrameCodec(model, max_batch=max_batch)
+    with torch.no_grad():
+        enc = fc.encode_video(frames, gop)
+        blob = fc.assemble_video(enc)
+        dec, data_dim, first, last = fc.decode_video(blob, cuda)
+        # idempotence of the container: re-assembling the parsed pieces gives the same bytes
+        dd, f0, f1, gops = cont.unpack_video(blob)
+        assert cont.pack_video(blob[:18], gops) == blob
+    assert data_dim['x'] == (h, w) and (first, last) == (0, n - 1) and len(dec) == n
+    rec = [r for g in enc['recs'] for r in g][:n]
+    for i, (d, e) in enumerate(zip(dec, rec)):
+        for k in 'yuv':
+            assert torch.equal(d[k], e[k]), (i, k)
+        assert d['y'].shape[-2:] == (h, w) and d['u'].shape[-2:] == ((h + 1) // 2, (w + 1) // 2)
+    return blob, enc, dec, frames
+
+
+def test_config2_all_intra_416x240(cuda):
+    blob, enc, dec, frames = _closed_loop(cuda, 416, 240, 4, '1_GOP_0')
+    # AI: 4 units of one I frame, each with two empty MOFNet sections
+    from aivc_amd.real_life import cat_binary_files as cont
+    from aivc_amd.real_life.bitstream import split_sections
+    _, _, _, gops = cont.unpack_video(blob)
+    assert len(gops) == 4
+    for g in gops:
+        name, rate, fr = cont.unpack_gop(g)
+        assert name == '1_GOP_0' and len(fr) == 1
+        s = split_sections(fr[0])
+        assert s[0] == b'' and s[1] == b'' and len(s[2]) > 0 and len(s[3]) > 0
+
+
+def test_config3_720p_low_delay_p(cuda):
+    _closed_loop(cuda, 1280, 720, 9, 'LDP_8')
+
+
+def test_config4_1080p_random_access(cuda):
+    _closed_loop(cuda, 1920, 1080, 9, '1_GOP_8')
+
+
+def test_config5_2160p(cuda):
+    _closed_loop(cuda, 3840, 2160, 3, '1_GOP_2', max_batch=2)
+
+
+def test_odd_frame_size_and_padding_of_last_unit(cuda):
+    # 7 frames with a 5-frame unit: the last unit is padded by repeating the last frame, the padded
+    # frames are dropped again by the decoder (src/model_mngt/model_management.py:148-153)
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    model = synth.make_model(arch.TINY_WIDTHS, seed=7, device=cuda)
+    blob, enc, dec, frames = _closed_loop(cuda, 97, 65, 7, '1_GOP_4', model=model)
+    assert enc['nb_gop'] == 2 and len(dec) == 7
+
+
+def test_all_zero_latents_and_saturated_latents(cuda):
+    """empty y sections (every map zero) and symbols clamped at the [-256, 255] limits survive."""
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from aivc_amd.real_life import cat_binary_files as cont
+    from aivc_amd.real_life.bitstream import split_sections
+    for scale in (0.0, 1e4):
+        model = synth.make_model(arch.TINY_WIDTHS, seed=7, device=cuda)
+        with torch.no_grad():
+            for net in (model.mode_net.mode_net, model.codec_net.codec_net):
+                last = [m for m in net.g_a.modules() if isinstance(m, torch.nn.Conv2d)][-1]
+                last.weight.mul_(scale)
+                last.bias.mul_(scale)
+        blob, enc, dec, frames = _closed_loop(cuda, 64, 48, 3, '1_GOP_2', model=model)
+        if scale == 0.0:
+            _, _, _, gops = cont.unpack_video(blob)
+            for fr in cont.unpack_gop(gops[0])[2]:
+                s = split_sections(fr)
+                assert s[3] == b'\x00' and s[1] in (b'', b'\x00')

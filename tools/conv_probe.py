@@ -15,13 +15,17 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     name, mode, k, s, pad, ci, co, h, w = PROBES[idx]
     dev = torch.device('cuda:0')
-    x = torch.randn(1, h, w, ci, device=dev)
+    nb = int(os.environ.get('BATCH', '1'))
+    x = torch.randn(nb, h, w, ci, device=dev)
     wt = torch.randn(co, k, k, ci, device=dev) * 0.05
     b = torch.rand(co, device=dev) + 0.5
     if mode in (abi.MODE_GDN, abi.MODE_IGDN):
         wt = wt.abs()
+    g = None
+    if os.environ.get('FUSE_GDN'):
+        g = (torch.rand(co, device=dev) + 0.5, torch.rand(co, co, device=dev) * 0.01, False)
     for _ in range(reps):
-        ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad)
+        ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g)
     torch.cuda.synchronize()
     print('probe', name)
 

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Pretty-print the JSON line of bench.py read from stdin."""
+import json
+import sys
+for line in sys.stdin:
+    line = line.strip()
+    if not line.startswith('{'):
+        continue
+    d = json.loads(line)
+    print('value %.3f %s | enc %.2f dec %.2f fps | ms/step %.1f | closed_loop %s | bytes/frame %.0f' % (
+        d['value'], d['unit'], d.get('encode_fps_rank0', 0), d.get('decode_fps_rank0', 0), d['ms_per_step'],
+        d.get('closed_loop_ok'), d.get('bytes_per_frame', 0)))
+    r = d.get('roofline')
+    if r:
+        print('roofline', r['kernel'], r['achieved'], r['unit'], 'frac', r['frac'], '| all mfma conv', r['all_mfma_conv'])
+        for k, v in r['per_variant'].items():
+            print('   %-34s %s' % (k, v))
+    if d.get('cpu_baseline'):
+        print('cpu_baseline', d['cpu_baseline'])
