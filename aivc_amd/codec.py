@@ -136,7 +136,7 @@ class FrameCodec:
     # so this yields the same bytes as the reference's depth-first order.
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=-1)  # entropy coder: few waves, latency critical
         return self._side
 
     def _chunks(self, gop, level, unit_ids):
@@ -191,18 +191,39 @@ class FrameCodec:
         for (gop_name, idx_rate), members in groups.items():
             gop = generate_gop_struct(gop_name)
             names = sorted(gop, key=frame_index)
-            lat = {}
-            for ftype in (FRAME_I, FRAME_P, FRAME_B):
-                items = [(i, f) for i in members for f in names if gop[f]['type'] == ftype]
-                for s0 in range(0, len(items), self.entropy_chunk):
-                    chunk = items[s0:s0 + self.entropy_chunk]
-                    yh = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype, data_dim,
-                                             idx_rate, device)
-                    for j, it in enumerate(chunk):
-                        lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
+            # entropy stage on the (high priority) side stream, one dependency level ahead of the
+            # synthesis stage on the main stream; the host alternates between the two so that both
+            # queues stay fed
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            levels = coding_levels(gop)
+            lat, ready = {}, {}
+
+            def issue_entropy(level):
+                for ftype in sorted({gop[f]['type'] for f in level}):
+                    items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
+                    for s0 in range(0, len(items), self.entropy_chunk):
+                        chunk = items[s0:s0 + self.entropy_chunk]
+                        with torch.cuda.stream(side):
+                            yh = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype,
+                                                     data_dim, idx_rate, device)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        for v in yh.values():
+                            if v is not None:
+                                v.record_stream(main)
+                        for j, it in enumerate(chunk):
+                            lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
+                            ready[it] = ev
+
             rec = {i: {} for i in members}
-            for level in coding_levels(gop):
+            issue_entropy(levels[0])
+            for li, level in enumerate(levels):
+                if li + 1 < len(levels):
+                    issue_entropy(levels[li + 1])
                 for ftype, chunk in self._chunks(gop, level, members):
+                    for ev in {id(ready[it]): ready[it] for it in chunk}.values():
+                        main.wait_event(ev)
                     yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
                           for k in ('mof', 'cod')}
                     dec = self.synthesise_batch(yh, [rec[i].get(gop[f]['prev_ref']) for i, f in chunk],

@@ -357,14 +357,27 @@ static int pick_tile(const aivc_conv_params &p) {
     if (co == 64) return blocks(256, 64) >= 384 ? 2 : 1;
     return 3;  // co == 32
   }
+  // score = measured efficiency class of the tile x how evenly its blocks fill the chip
+  // (resident blocks: 128x128 -> 3 per CU, 64x64 -> 6, 256x64 and 256x128 -> 2)
+  const int taps = t ? (p.ksize * p.ksize + 3) / 4 : p.ksize * p.ksize;
+  const long kred = (long)taps * p.c_in;
+  auto score = [&](int bm, int bn, int slots, double base) {
+    const long b = blocks(bm, bn);
+    const long rounds = (b + slots - 1) / slots;
+    return base * (double)b / (double)(rounds * slots);
+  };
   if (co > 64) {
-    // 64x128 per wave (half the staging per FLOP) pays off when the reduction is long enough to
-    // amortise the bigger prologue/epilogue and there are >= 2 rounds of blocks
-    const int taps = t ? (p.ksize * p.ksize + 3) / 4 : p.ksize * p.ksize;
-    if (co % 128 == 0 && taps * p.c_in >= 1024 && blocks(256, 128) >= 1024) return 4;
-    return blocks(128, 128) >= 384 ? 0 : 1;
+    double best = score(128, 128, 768, 0.80);
+    int tile = 0;
+    const double s1 = score(64, 64, 1536, 0.60);
+    if (s1 > best) best = s1, tile = 1;
+    if (!t && co % 128 == 0 && kred >= 512) {  // (transposed conv: the 4 parity classes have unequal K)
+      const double s4 = score(256, 128, 512, kred >= 1024 ? 0.95 : 0.86);
+      if (s4 > best) best = s4, tile = 4;
+    }
+    return tile;
   }
-  if (co > 32) return blocks(256, 64) >= 384 ? 2 : 1;
+  if (co > 32) return score(256, 64, 512, 0.78) >= score(64, 64, 1536, 0.60) ? 2 : 1;
   return 3;
 }
 

@@ -177,6 +177,8 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
+  // latency-critical serial wave: win the issue arbitration against co-resident conv waves
+  __builtin_amdgcn_s_setprio(3);
   BitSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, 0};
   uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
   const uint32_t *src = bounds + st.in_off;
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
   if (st.n_sym == 0) return;
+  __builtin_amdgcn_s_setprio(3);  // latency-critical serial wave (see range_encode_kernel)
   BitSrc src;
   src.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
   src.n_words = (st.in_len + 3u) / 4u;
