@@ -33,7 +33,7 @@ struct MfmaArgs {
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
 __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int UA = BM * 4 / 256;          // (row, octet) units per thread for A
@@ -96,7 +96,60 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     tx = tap - ty * nkx;
   };
 
-  auto load_tile = [&](int kt) {
+  // FASTK (c_in % 32 == 0): a K-tile lies inside one kernel tap, K % 32 == 0, so the loader is
+  // branch-free: one clamped pixel address per unit, two 16-byte loads off it, weights by pointer
+  // bump.  Out-of-image taps of the transposed conv are loaded from a clamped address and zeroed.
+  uint32_t b_off[UB];
+  bool b_ok[UB];
+#pragma unroll
+  for (int j = 0; j < UB; ++j) {
+    const int u = tid + 256 * j;
+    const int co = n0 + (u >> 2);
+    b_ok[j] = u < BN * 4;
+    const int coc = co < Cout ? co : Cout - 1;  // clamped: rows beyond c_out are never stored
+    b_off[j] = TCONV ? (uint32_t)coc * (uint32_t)(ks * ks * Cin) + (uint32_t)((u & 3) * 8)
+                     : (uint32_t)coc * (uint32_t)K + (uint32_t)((u & 3) * 8);
+  }
+  auto load_tile_fast = [&](int kt) {
+    const int kbase = kt * BK;
+    int ty, tx, ci0;
+    tap_of(kbase, ty, tx, ci0);  // wave-uniform
+    const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
+#pragma unroll
+    for (int j = 0; j < UA; ++j) {
+      int iy = a_by[j] + (TCONV ? dyt : ty), ix = a_bx[j] + (TCONV ? dxt : tx);
+      bool ok = true;
+      if (TCONV) ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+      const float *src = p.x + ((a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(ci0 + ((tid + 256 * j) & 3) * 8));
+      float4 v0 = *reinterpret_cast<const float4 *>(src);
+      float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+      if (TCONV) {
+        const float z = ok ? 1.0f : 0.0f;  // select, not multiply: avoids NaN * 0
+        v0 = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+        v1 = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+        (void)z;
+      }
+      if (GDN) {
+        v0.x *= v0.x; v0.y *= v0.y; v0.z *= v0.z; v0.w *= v0.w;
+        v1.x *= v1.x; v1.y *= v1.y; v1.z *= v1.z; v1.w *= v1.w;
+      }
+      ra[j][0] = v0;
+      ra[j][1] = v1;
+    }
+    const uint32_t wk = TCONV ? (uint32_t)(((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0) : (uint32_t)kbase;
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (b_ok[j]) {
+        const float *src = p.w + (b_off[j] + wk);
+        rb[j][0] = *reinterpret_cast<const float4 *>(src);
+        rb[j][1] = *reinterpret_cast<const float4 *>(src + 4);
+      }
+    }
+  };
+
+  auto load_tile_generic = [&](int kt) {
     const int kbase = kt * BK;
     int fty = 0, ftx = 0, fci = 0;
     if (fast) tap_of(kbase, fty, ftx, fci);
@@ -172,6 +225,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
         rb[j][q] = v;
       }
     }
+  };
+  auto load_tile = [&](int kt) {
+    if constexpr (FASTK) load_tile_fast(kt);
+    else load_tile_generic(kt);
   };
 
   auto store_tile = [&]() {
@@ -332,8 +389,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
-static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
+static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   MfmaArgs a;
   a.p = p;
@@ -341,8 +398,14 @@ static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   a.cin_magic = (uint32_t)((0x100000000ull + (uint64_t)p.c_in - 1) / (uint64_t)p.c_in);
   dim3 grid((a.M + BM - 1) / BM, (p.c_out + BN - 1) / BN, MODE == AIVC_MODE_TCONV ? 4 : 1);
   const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
+static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
+  if (p.c_in % BK == 0) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true>(p, s);
+  return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, false>(p, s);
 }
 
 // tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128
