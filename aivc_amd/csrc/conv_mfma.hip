@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   }
   const int K = nky * nkx * Cin;
   const int nkt = (K + BK - 1) / BK;
-  const bool fast = (Cin % BK) == 0;  // a K-tile never straddles two taps
   const uint32_t inv_nkx = (65536u + nkx - 1) / nkx;
 
   // ---- per-thread loader units ------------------------------------------------------------
@@ -149,48 +148,39 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     }
   };
 
+  // generic path (small c_in: a K-tile straddles taps, K has a zero-padded tail): still branch-free --
+  // every address is clamped to something valid and the value is zeroed by a select.
   auto load_tile_generic = [&](int kt) {
     const int kbase = kt * BK;
-    int fty = 0, ftx = 0, fci = 0;
-    if (fast) tap_of(kbase, fty, ftx, fci);
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
       const int oct = (tid + 256 * j) & 3;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int kk = kbase + oct * 8 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < K) {
-          int ty, tx, ci;
-          if (fast) {
-            ty = fty;
-            tx = ftx;
-            ci = fci + oct * 8 + q * 4;
-          } else {
-            tap_of(kk, ty, tx, ci);
-          }
-          int iy, ix;
-          bool ok = true;
-          if (TCONV) {
-            iy = a_by[j] + ((pyc + tpad - (ky0 + 2 * ty)) >> 1);
-            ix = a_bx[j] + ((pxc + tpad - (kx0 + 2 * tx)) >> 1);
-            ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          } else {
-            iy = a_by[j] + ty;
-            ix = a_bx[j] + tx;
-            iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
-            ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
-          }
-          if (ok) {
-            const uint32_t off = (a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)ci;
-            v = *reinterpret_cast<const float4 *>(p.x + off);
-            if (GDN) {
-              v.x = v.x * v.x;
-              v.y = v.y * v.y;
-              v.z = v.z * v.z;
-              v.w = v.w * v.w;
-            }
-          }
+        const int kc = kk < K ? kk : K - 4;
+        int ty, tx, ci;
+        tap_of(kc, ty, tx, ci);
+        int iy, ix;
+        bool ok = kk < K;
+        if (TCONV) {
+          iy = a_by[j] + ((pyc + tpad - (ky0 + 2 * ty)) >> 1);
+          ix = a_bx[j] + ((pxc + tpad - (kx0 + 2 * tx)) >> 1);
+          ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        } else {
+          iy = a_by[j] + ty;
+          ix = a_bx[j] + tx;
+        }
+        iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+        const uint32_t off = (a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)ci;
+        float4 v = *reinterpret_cast<const float4 *>(p.x + off);
+        v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GDN) {
+          v.x = v.x * v.x;
+          v.y = v.y * v.y;
+          v.z = v.z * v.z;
+          v.w = v.w * v.w;
         }
         ra[j][q] = v;
       }
@@ -198,31 +188,25 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const int u = tid + 256 * j;
-      const int row = u >> 2, oct = u & 3;
-      const int co = n0 + row;
+      const int oct = u & 3;
+      const int co = n0 + (u >> 2);
+      const int coc = co < Cout ? co : Cout - 1;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int kk = kbase + oct * 8 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u < BN * 4 && kk < K && co < Cout) {
-          uint32_t off;
-          if (TCONV) {
-            int ty, tx, ci;
-            if (fast) {
-              ty = fty;
-              tx = ftx;
-              ci = fci + oct * 8 + q * 4;
-            } else {
-              tap_of(kk, ty, tx, ci);
-            }
-            off = ((uint32_t)co * (uint32_t)(ks * ks) + (uint32_t)((ky0 + 2 * ty) * ks + kx0 + 2 * tx)) * (uint32_t)Cin +
-                  (uint32_t)ci;
-          } else {
-            off = (uint32_t)co * (uint32_t)K + (uint32_t)kk;
-          }
-          v = *reinterpret_cast<const float4 *>(p.w + off);
+        const int kc = kk < K ? kk : K - 4;
+        uint32_t off;
+        if (TCONV) {
+          int ty, tx, ci;
+          tap_of(kc, ty, tx, ci);
+          off = ((uint32_t)coc * (uint32_t)(ks * ks) + (uint32_t)((ky0 + 2 * ty) * ks + kx0 + 2 * tx)) * (uint32_t)Cin +
+                (uint32_t)ci;
+        } else {
+          off = (uint32_t)coc * (uint32_t)K + (uint32_t)kc;
         }
-        rb[j][q] = v;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b_ok[j]) v = *reinterpret_cast<const float4 *>(p.w + off);
+        rb[j][q] = (kk < K && co < Cout) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
