@@ -76,6 +76,7 @@ PROTOTYPES = {
     'aivc_warp': [_f, _f, _i32, _i32, _i32, _i32, _f],
     'aivc_hyper_params': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f],
     'aivc_channel_gain': [_f, _f, _sz, _i32, _f],
+    'aivc_gain_interp': [_f, _f, _i32, _fl, _f],
     'aivc_quantize_center': [_f, _f, _f, _sz, _i32, _f, _f],
     'aivc_dequantize': [_f, _f, _f, _sz, _i32, _f],
     'aivc_balle_cdf_table': [_f, _i32, _f, _f],

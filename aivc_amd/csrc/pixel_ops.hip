@@ -232,6 +232,12 @@ __global__ __launch_bounds__(256) void channel_gain_kernel(const float *__restri
   out[gid] = gain ? in[gid] * __builtin_fabsf(gain[gid % c]) : in[gid];
 }
 
+__global__ __launch_bounds__(256) void gain_interp_kernel(const float *__restrict__ g_r, const float *__restrict__ g_t,
+                                                          int c, float l, float *__restrict__ out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch < c) out[ch] = aivc_gain_interp_one(g_r[ch], g_t[ch], l);
+}
+
 __global__ __launch_bounds__(256) void quantize_center_kernel(const float *__restrict__ y, const float *__restrict__ mu,
                                                               const float *__restrict__ gain, size_t total, int c,
                                                               int16_t *__restrict__ q, float *__restrict__ y_hat) {
@@ -378,6 +384,13 @@ AIVC_EXPORT int aivc_channel_gain(const float *in, const float *gain, size_t npi
   hipLaunchKernelGGL(channel_gain_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), in, gain,
                      npix * c, c, out);
   return check_launch("channel_gain");
+}
+
+AIVC_EXPORT int aivc_gain_interp(const float *g_r, const float *g_t, int32_t c, float l, float *out,
+                                 aivc_stream_t stream) {
+  if (!g_r || !g_t || !out || c <= 0) return AIVC_ERR_ARG;
+  hipLaunchKernelGGL(gain_interp_kernel, dim3(cdiv(c, 256)), dim3(256), 0, to_stream(stream), g_r, g_t, c, l, out);
+  return check_launch("gain_interp");
 }
 
 AIVC_EXPORT int aivc_quantize_center(const float *y, const float *mu, const float *gain_dec, size_t npix, int32_t c,

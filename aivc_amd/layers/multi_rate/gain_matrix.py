@@ -38,9 +38,17 @@ class GainMatrix(Module):
         return (self.get_gain(prev_i, mode) ** lam) * (self.get_gain(next_i, mode) ** (1 - lam))
 
     def gain_vector(self, idx_rate, mode):
+        """[C] gain used by the codec: the parameter itself for an integer rate index (|.| is applied
+        by the kernels), else the deterministic interpolation kernel (aivc_gain_interp)."""
         if float(idx_rate) == int(idx_rate):
             return self.get_gain(int(idx_rate), mode).detach().reshape(-1)
-        return self.interpolate_gain_vector(idx_rate, mode).detach().reshape(-1)
+        lst = {'enc': self.enc_gain_list, 'dec': self.dec_gain_list}[mode]
+        prev_i = int(np.floor(idx_rate))
+        next_i = prev_i + 1 if prev_i + 1 < len(lst) else prev_i
+        lam = 1 - (idx_rate - prev_i)
+        if not lst[prev_i].is_cuda:
+            return self.interpolate_gain_vector(idx_rate, mode).detach().reshape(-1)  # API use on CPU params
+        return ops.gain_interp(lst[prev_i], lst[next_i], lam)
 
     def forward(self, param):
         default = {'x': None, 'idx_rate': 0., 'mode': None}

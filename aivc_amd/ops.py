@@ -247,6 +247,14 @@ def channel_gain(x, gain):
     return out
 
 
+def gain_interp(g_r, g_t, lam):
+    g_r = _dev(g_r.detach().reshape(-1), torch.float32, 'g_r')
+    g_t = _dev(g_t.detach().reshape(-1), torch.float32, 'g_t')
+    out = torch.empty_like(g_r)
+    call('aivc_gain_interp', _p(g_r), _p(g_t), g_r.numel(), float(lam), _p(out), _stream())
+    return out
+
+
 def quantize_center(y, mu=None, gain_dec=None, want_yhat=True):
     y = _dev(y, torch.float32, 'y')
     mu = _dev(mu, torch.float32, 'mu')

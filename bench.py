@@ -113,7 +113,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get('AIVC_FORCE_DIST'))  # (the env var exercises the RCCL path on 1 GPU)
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
     from aivc_amd import ops, synth
@@ -124,7 +125,7 @@ def main():
     seed = 1234
     model = synth.make_model(widths, seed=seed, device=dev)
     synth.calibrate_operating_point(model, dev)
-    if world > 1:
+    if use_dist:
         broadcast_model(model)  # the one collective: weights over RCCL/xGMI
     from aivc_amd.codec import FrameCodec
     fc = FrameCodec(model, max_batch=args.max_batch)
@@ -161,7 +162,7 @@ def main():
         closed_loop &= all(torch.equal(d[k], e[k]) for d, e in zip(dec, rec) for k in 'yuv')
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
     barrier()
     torch.cuda.synchronize()
@@ -171,7 +172,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -243,7 +244,7 @@ def main():
         if args.tiny:
             out['invalid'] = 'tiny debug model'
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -184,6 +184,18 @@ AIVC_HD float aivc_softplusf_det(float x) {
   return (float)aivc_det_log1p(aivc_det_exp((double)x));
 }
 
+/* torch.pow(float tensor, python float) for a > 0 */
+AIVC_HD float aivc_powf_det(float a, float e) {
+  if (e == 0.0f) return 1.0f;
+  if (e == 1.0f) return a;
+  if (a == 0.0f) return 0.0f;
+  return (float)aivc_det_exp((double)e * aivc_det_log((double)a));
+}
+AIVC_HD float aivc_gain_interp_one(float g_r, float g_t, float l) {
+  const float a = g_r < 0.0f ? -g_r : g_r, b = g_t < 0.0f ? -g_t : g_t;
+  return aivc_powf_det(a, l) * aivc_powf_det(b, 1.0f - l);
+}
+
 /* Laplace(0, sigma/sqrt(2)).cdf(t) in the reference's fp32 op order
  * (torch.distributions.Laplace.cdf: 0.5 - 0.5 * sign(t) * expm1(-|t| / b)). */
 AIVC_HD float aivc_laplace_cdf(float t, float sigma) {

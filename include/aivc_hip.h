@@ -193,6 +193,12 @@ int aivc_hyper_params(const float *hs, int32_t n, int32_t hh, int32_t wh, int32_
 int aivc_channel_gain(const float *in, const float *gain, size_t npix, int32_t c, float *out,
                       aivc_stream_t stream);
 
+/* Fractional rate index (GainMatrix.interpolate_gain_vector, src/layers/multi_rate/gain_matrix.py:159-194):
+ * out[ch] = fp32(|g_r[ch]| ^ l) * fp32(|g_t[ch]| ^ (1 - l)), powers evaluated as det_exp(l * det_log(.)) in
+ * fp64 so that encoder and decoder derive the same gains on any machine. */
+int aivc_gain_interp(const float *g_r, const float *g_t, int32_t c, float l, float *out,
+                     aivc_stream_t stream);
+
 /* Encoder side: q = clamp(rint(y - mu), -256, 255) (half-to-even); y_hat = (q + mu) * |gain_dec|.
  * mu == NULL means mu = 0 (the z latent); gain_dec == NULL means gain 1.  q (int16) and y_hat
  * may each be NULL.  Replaces Quantizer (src/layers/misc/misc_layers.py:162-169) and the

@@ -78,7 +78,12 @@ def split_lp(blob, pos, count):
 # ---- conditional coder ----------------------------------------------------------------------------
 def _gain(net, frame_type, mode, idx_rate=0):
     key = 'I' if (not net['flag_gain_p_b'] or frame_type == FRAME_I) else ('P' if frame_type == FRAME_P else 'B')
-    return net['gain'][key][mode][int(idx_rate)]
+    lst = net['gain'][key][mode]
+    if float(idx_rate) == int(idx_rate):
+        return lst[int(idx_rate)]
+    prev_i = int(math.floor(idx_rate))
+    next_i = prev_i + 1 if prev_i + 1 < len(lst) else prev_i
+    return O.gain_interp(lst[prev_i], lst[next_i], 1 - (idx_rate - prev_i))
 
 
 def _shortcut(net, in_shortcut, h_y, w_y):
@@ -99,21 +104,21 @@ def _y_section(sigma, q_y):
     return body
 
 
-def cond_encode(net, x_in, in_shortcut, frame_type):
+def cond_encode(net, x_in, in_shortcut, frame_type, idx_rate=0.):
     y = O.run_layer(net['g_a'], x_in)
-    y = O.channel_gain(y, _gain(net, frame_type, 'enc'))
+    y = O.channel_gain(y, _gain(net, frame_type, 'enc', idx_rate))
     z = O.run_layer(net['h_a'], y)
     q_z, z_hat = O.quantize_center(z)
     h_y, w_y = y.shape[1:3]
     mu, sigma = O.hyper_params(O.run_layer(net['h_s'], z_hat), net['c_y'], h_y, w_y)
-    q_y, y_hat = O.quantize_center(y, mu, _gain(net, frame_type, 'dec'))
+    q_y, y_hat = O.quantize_center(y, mu, _gain(net, frame_type, 'dec', idx_rate))
     table, _ = O.balle_cdf_table(net['balle'])
     s = _shortcut(net, in_shortcut, h_y, w_y)
     x_out = O.run_layer(net['g_s'], np.concatenate((y_hat, s), axis=3))
     return x_out, _z_section(table, q_z), _y_section(sigma, q_y), (h_y, w_y), tuple(z.shape[1:3])
 
 
-def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z):
+def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z, idx_rate=0.):
     """src/real_life/decode.py:798-898"""
     table, _ = O.balle_cdf_table(net['balle'])
     c_z, c_y = net['c_z'], net['c_y']
@@ -130,7 +135,7 @@ def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z):
         q_y = O.scatter_symbols(sym, npy, c_y, maps).reshape(1, dim_y[0], dim_y[1], c_y)
     else:
         q_y = np.zeros((1, dim_y[0], dim_y[1], c_y), np.int16)
-    y_hat = O.dequantize(q_y, mu, _gain(net, frame_type, 'dec'))
+    y_hat = O.dequantize(q_y, mu, _gain(net, frame_type, 'dec', idx_rate))
     s = _shortcut(net, in_shortcut, dim_y[0], dim_y[1])
     return O.run_layer(net['g_s'], np.concatenate((y_hat, s), axis=3))
 
@@ -147,7 +152,7 @@ def _rec(cod_out, h, w, skip):
     return {'y': y8[0], 'u': u8[0], 'v': v8[0]}
 
 
-def encode_frame(model, cur, prev, nxt, frame_type):
+def encode_frame(model, cur, prev, nxt, frame_type, idx_rate=0.):
     h, w = cur['y'].shape
     code = to444(cur, h, w)
     secs = [b'', b'', None, None]
@@ -157,19 +162,19 @@ def encode_frame(model, cur, prev, nxt, frame_type):
         p444, n444 = to444(prev, h, w), to444(nxt if frame_type == FRAME_B else None, h, w)
         short_in = np.concatenate((p444, n444), axis=3) if frame_type == FRAME_B else None
         mof_out, secs[0], secs[1], _, _ = cond_encode(model['mof'], np.concatenate((code, p444, n444), axis=3),
-                                                      short_in, frame_type)
+                                                      short_in, frame_type, idx_rate)
         empty[0] = empty[1] = False
         wb = O.warp_blend(mof_out, p444, n444, h, w, frame_type, co=3)
         pred, skip = wb['pred'], wb['skip']
     zero = np.zeros_like(code) if pred is None else pred
     cod_out, secs[2], secs[3], dim_y, dim_z = cond_encode(model['cod'], np.concatenate((code, zero), axis=3), pred,
-                                                          frame_type)
+                                                          frame_type, idx_rate)
     frame = b''.join(be(0, 4) if empty[i] else lp(secs[i]) for i in range(4))
     data_dim = {'x': (h, w), 'y': dim_y, 'z': dim_z}
     return frame, _rec(cod_out, h, w, skip), data_dim
 
 
-def decode_frame(model, frame_bytes, prev, nxt, frame_type, data_dim):
+def decode_frame(model, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0.):
     """src/real_life/decode.py:455-580"""
     h, w = data_dim['x']
     sec = split_lp(frame_bytes, 0, 4)
@@ -177,10 +182,10 @@ def decode_frame(model, frame_bytes, prev, nxt, frame_type, data_dim):
     if frame_type != FRAME_I:
         p444, n444 = to444(prev, h, w), to444(nxt if frame_type == FRAME_B else None, h, w)
         short_in = np.concatenate((p444, n444), axis=3) if frame_type == FRAME_B else None
-        mof_out = cond_decode(model['mof'], sec[0], sec[1], short_in, frame_type, data_dim['y'], data_dim['z'])
+        mof_out = cond_decode(model['mof'], sec[0], sec[1], short_in, frame_type, data_dim['y'], data_dim['z'], idx_rate)
         wb = O.warp_blend(mof_out, p444, n444, h, w, frame_type, co=3)
         pred, skip = wb['pred'], wb['skip']
-    cod_out = cond_decode(model['cod'], sec[2], sec[3], pred, frame_type, data_dim['y'], data_dim['z'])
+    cod_out = cond_decode(model['cod'], sec[2], sec[3], pred, frame_type, data_dim['y'], data_dim['z'], idx_rate)
     return _rec(cod_out, h, w, skip)
 
 
@@ -197,7 +202,7 @@ def encode_video(model, frames, gop_name, first=0, idx_rate=0.):
         rec, fb = {}, {}
         for i in order:
             t, p, nx, _ = g[i]
-            fb[i], rec[i], data_dim = encode_frame(model, chunk[i], rec.get(p), rec.get(nx), t)
+            fb[i], rec[i], data_dim = encode_frame(model, chunk[i], rec.get(p), rec.get(nx), t, idx_rate)
         gops.append(gop_header(gop_name, idx_rate) + b''.join(lp(fb[i]) for i in sorted(g)))
         recs.extend(rec[i] for i in sorted(g))
     blob = video_header(data_dim, nb_gop, first, first + n - 1) + b''.join(lp(x) for x in gops)
@@ -212,11 +217,12 @@ def decode_video(model, blob):
     for gb in split_lp(blob, 18, nb_gop):
         ldp, chain, size = bool(gb[0]), int.from_bytes(gb[1:3], 'big'), int.from_bytes(gb[3:5], 'big')
         name = 'LDP_%d' % size if ldp else '%d_GOP_%d' % (chain, size)
+        idx_rate = gb[5] / 16
         g = gop_struct(name)
         fbytes = split_lp(gb, 6, len(g))
         rec = {}
         for i in sorted(g, key=lambda i: g[i][3]):
             t, p, nx, _ = g[i]
-            rec[i] = decode_frame(model, fbytes[i], rec.get(p), rec.get(nx), t, data_dim)
+            rec[i] = decode_frame(model, fbytes[i], rec.get(p), rec.get(nx), t, data_dim, idx_rate)
         out.extend(rec[i] for i in sorted(g))
     return out[:last - first + 1]

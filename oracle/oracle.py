@@ -230,6 +230,13 @@ def channel_gain(x, gain):
     return out
 
 
+def gain_interp(g_r, g_t, lam):
+    g_r, g_t = _f32(g_r).reshape(-1), _f32(g_t).reshape(-1)
+    out = np.empty_like(g_r)
+    _chk(lib()['aivc_gain_interp'](_p(g_r), _p(g_t), g_r.size, float(lam), _p(out), None), 'aivc_gain_interp')
+    return out
+
+
 def quantize_center(y, mu=None, gain_dec=None):
     y = _f32(y)
     mu = None if mu is None else _f32(mu)

@@ -155,3 +155,68 @@ def test_all_zero_latents_and_saturated_latents(cuda):
             for fr in cont.unpack_gop(gops[0])[2]:
                 s = split_sections(fr)
                 assert s[3] == b'\x00' and s[1] in (b'', b'\x00')
+
+
+def test_fractional_rate_index_matches_oracle(cuda):
+    """idx_rate = 0.5 / 1.25: gains interpolated by aivc_gain_interp, the index travels in the GOP header"""
+    from aivc_amd import synth
+    from aivc_amd.model_mngt.model_management import attach_arithmetic_coders
+    from aivc_amd.models import arch
+    from aivc_amd.models.full_net import FullNet
+    from oracle import codec as ocodec
+    from oracle import spec as ospec
+    torch.manual_seed(5)
+    model = FullNet({'widths': arch.TINY_WIDTHS, 'nb_rates': 3, 'lambda_tradeoff': [0.01, 0.02, 0.04]})
+    gen = torch.Generator().manual_seed(5)
+    synth._init_weights(model, gen)
+    model = attach_arithmetic_coders(model.eval().to(cuda))
+    frames = synth.synthetic_video(64, 48, 3, seed=4)
+    fc = model.frame_codec()
+    for rate in (0.5, 1.25, 2.0):
+        with torch.no_grad():
+            enc = fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2', idx_rate=rate)
+            blob = fc.assemble_video(enc)
+            dec, _, _, _ = fc.decode_video(blob, cuda)
+        ref_blob, ref_rec = ocodec.encode_video(ospec.export_model(model), frames, '1_GOP_2', idx_rate=rate)
+        assert blob == ref_blob
+        for d, r in zip(dec, ref_rec):
+            for k in 'yuv':
+                np.testing.assert_array_equal(d[k][0].cpu().numpy(), r[k])
+
+
+def test_reference_style_api_round_trip(cuda, tmp_path):
+    """FullNet.GOP_forward (dict in, files out) -> cat_one_video -> Decoder.decode per frame / decode_one_video:
+    the path-based API of the reference on top of the in-memory codec."""
+    from aivc_amd import synth
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    from aivc_amd.model_mngt.model_management import infer_one_sequence
+    from aivc_amd.models import arch
+    from aivc_amd.real_life import cat_binary_files as cont
+    from aivc_amd.real_life.decode import Decoder, decode_one_video
+    model = synth.make_model(arch.TINY_WIDTHS, seed=7, device=cuda)
+    frames = synth.synthetic_video(64, 48, 5, seed=3)
+    video = [{k: torch.from_numpy(f[k]).float().div(255.).view(1, 1, *f[k].shape) for k in 'yuv'} for f in frames]
+    out_bin = str(tmp_path / 'out' / 'video.bin')
+    infer_one_sequence({'model': model, 'GOP_struct': generate_gop_struct('1_GOP_2'), 'GOP_struct_name': '1_GOP_2',
+                        'raw_video': video, 'idx_starting_frame': 0, 'idx_end_frame': 4, 'generate_bitstream': True,
+                        'bitstream_dir': str(tmp_path / 'bs'), 'final_bitstream_path': out_bin})
+    blob = open(out_bin, 'rb').read()
+    fc = model.frame_codec()
+    with torch.no_grad():
+        ref = fc.assemble_video(fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2'))
+    assert blob == ref
+    dec = Decoder({'full_net': model}).eval()
+    out_yuv = str(tmp_path / 'dec.yuv')
+    got = decode_one_video({'decoder': dec, 'bitstream_path': out_bin, 'device': 'cuda:0', 'out_file': out_yuv})
+    assert len(got) == 5
+    raw = np.fromfile(out_yuv, np.uint8)
+    assert raw.size == 5 * (64 * 48 + 2 * 32 * 24)
+    # Decoder.decode on one frame file (I frame of the first GOP)
+    data_dim, first, last, gops = cont.unpack_video(blob)
+    name, rate, fr = cont.unpack_gop(gops[0])
+    fpath = str(tmp_path / '0')
+    open(fpath, 'wb').write(fr[0])
+    rec = dec.decode({'prev_dic': None, 'next_dic': None, 'frame_type': 0, 'bitstream_path': fpath, 'data_dim': data_dim,
+                      'device': 'cuda:0'})
+    assert torch.equal((rec['y'] * 255).round().to(torch.uint8)[0], got[0]['y'])
+    np.testing.assert_array_equal(raw[:64 * 48].reshape(48, 64), got[0]['y'][0].cpu().numpy())

@@ -130,6 +130,11 @@ def test_gain_matrix(oracle, golden):
                 np.testing.assert_array_equal(nhwc_to_nchw(y), ref)
             else:
                 close(nhwc_to_nchw(y), ref, rtol=1e-6, atol=1e-7)
+                # the codec's deterministic interpolation (aivc_gain_interp) against the reference's pow
+                lst = gm.enc_gain_list if mode == 'enc' else gm.dec_gain_list
+                pi = int(np.floor(idx))
+                g2 = oracle.gain_interp(lst[pi].detach().numpy(), lst[min(pi + 1, 2)].detach().numpy(), 1 - (idx - pi))
+                close(nhwc_to_nchw(oracle.channel_gain(x, g2)), ref, rtol=1e-6, atol=1e-7)
 
 
 def test_quantizer(oracle, golden):
