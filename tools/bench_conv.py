@@ -37,19 +37,23 @@ def main():
         ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
         taps = k * k if mode != abi.MODE_TCONV else k * k / 4.0
         flops = 2.0 * taps * ci * co * ho * wo * nb
-        for algo in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_MFMA, abi.ALGO_AUTO]):
+        variants = [(a, None) for a in ([abi.ALGO_AUTO] if co >= 16 else [abi.ALGO_MFMA, abi.ALGO_AUTO])]
+        if co in (64, 128) and mode in (abi.MODE_CONV, abi.MODE_TCONV):
+            variants.append((abi.ALGO_AUTO, (torch.rand(co, device=dev) + 0.5, torch.rand(co, co, device=dev) * 0.01, False)))
+        for algo, g in variants:
+            fl = flops + (2.0 * co * co * ho * wo * nb if g is not None else 0.0)
             for _ in range(2):
-                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)
+                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo, gdn=g)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = 5
             e0.record()
             for _ in range(n):
-                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo)
+                ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo, gdn=g)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
-            print('%-32s algo=%d  %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, ms, flops / 1e9, flops / ms / 1e9))
+            print('%-32s algo=%d %s %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, '+gdn' if g is not None else '    ', ms, fl / 1e9, fl / ms / 1e9))
         tot_f += flops
         tot_t += ms
     print('sum: %.1f GFLOP in %.2f ms -> %.1f TFLOP/s' % (tot_f / 1e9, tot_t, tot_f / tot_t / 1e9))
