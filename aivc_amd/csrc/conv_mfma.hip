@@ -18,6 +18,8 @@
 //                  dense conv over the taps of that parity with zero fill outside the image.
 //   epilogue       bias / GDN division / activation / gate / residual fused, straight from the
 //                  accumulators (lanes 0-31 of a row write 128 contiguous bytes).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace aivc {
@@ -392,40 +394,54 @@ static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, false>(p, s);
 }
 
-// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128
+// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128, 5 = 64x128
+static int pick_tile_auto(const aivc_conv_params &p);
 static int pick_tile(const aivc_conv_params &p) {
+  // tuning aid: AIVC_FORCE_TILE=<id> overrides the choice when that tile can run the shape
+  if (const char *e = getenv("AIVC_FORCE_TILE")) {
+    const int t = atoi(e);
+    const int bn = t == 0 || t == 4 || t == 5 ? 128 : (t == 3 ? 32 : 64);
+    if (t >= 0 && t <= 5 && (!p.gdn || (bn == p.c_out && t != 4))) return t;
+  }
+  return pick_tile_auto(p);
+}
+static int pick_tile_auto(const aivc_conv_params &p) {
   const bool t = p.mode == AIVC_MODE_TCONV;
   const long M = t ? (long)p.n * p.h_in * p.w_in : (long)p.n * p.h_out * p.w_out;
   const int z = t ? 4 : 1;
   const int co = p.c_out;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((co + bn - 1) / bn) * z; };
-  if (p.gdn) {  // fused (I)GDN: the tile must span all output channels (BN == c_out)
-    if (co == 128) return 0;
-    if (co == 64) return blocks(256, 64) >= 384 ? 2 : 1;
-    return 3;  // co == 32
-  }
-  // score = measured efficiency class of the tile x how evenly its blocks fill the chip
-  // (resident blocks: 128x128 -> 3 per CU, 64x64 -> 6, 256x64 and 256x128 -> 2)
   const int taps = t ? (p.ksize * p.ksize + 3) / 4 : p.ksize * p.ksize;
   const long kred = (long)taps * p.c_in;
+  // Measured on MI355X (tools/bench_conv.py, batch 8): every tile saturates at 105-117 TFLOP/s on
+  // long reductions; what differs is how well short reductions / few blocks are hidden, where
+  // the small 64x64 tile (6 workgroups per CU) wins.  Rules:
+  //   c_out <= 64            -> 64x64 (also with fused GDN: BN == c_out)
+  //   c_out  = 32            -> 128x32
+  //   fused GDN, c_out = 128 -> 128x128, or 64x128 for the short reductions of a transposed 3x3
+  //   otherwise score the candidates by efficiency class x block-count balance
+  if (co <= 32) return 3;
+  if (co <= 64) return 1;
+  if (p.gdn) return (t && p.ksize == 3) ? 5 : 0;  // BN must equal c_out = 128
   auto score = [&](int bm, int bn, int slots, double base) {
     const long b = blocks(bm, bn);
     const long rounds = (b + slots - 1) / slots;
     return base * (double)b / (double)(rounds * slots);
   };
-  if (co > 64) {
-    double best = score(128, 128, 768, 0.80);
-    int tile = 0;
-    const double s1 = score(64, 64, 1536, 0.60);
-    if (s1 > best) best = s1, tile = 1;
-    if (!t && co % 128 == 0 && kred >= 512) {  // (transposed conv: the 4 parity classes have unequal K)
-      const double s4 = score(256, 128, 512, kred >= 1024 ? 0.95 : 0.86);
-      if (s4 > best) best = s4, tile = 4;
-    }
-    return tile;
+  if (p.mode == AIVC_MODE_GDN || p.mode == AIVC_MODE_IGDN) return 1;
+  double best = score(128, 128, 768, 0.80);
+  int tile = 0;
+  const double s1 = score(64, 64, 1536, kred <= 256 ? 0.85 : 0.74);
+  if (s1 > best) best = s1, tile = 1;
+  if (t && p.ksize == 3) {
+    const double s5 = score(64, 128, 1024, 0.86);
+    if (s5 > best) best = s5, tile = 5;
   }
-  if (co > 32) return score(256, 64, 512, 0.78) >= score(64, 64, 1536, 0.60) ? 2 : 1;
-  return 3;
+  if (!t && co % 128 == 0 && kred >= 512) {  // (transposed conv: the 4 parity classes have unequal K)
+    const double s4 = score(256, 128, 512, kred >= 1024 ? 0.95 : 0.86);
+    if (s4 > best) best = s4, tile = 4;
+  }
+  return tile;
 }
 
 template <int MODE>
@@ -437,6 +453,7 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
         case 0: return launch_cfg<MODE, 2, 2, 2, 2, true>(p, s);
         case 1: return launch_cfg<MODE, 2, 2, 1, 1, true>(p, s);
         case 2: return launch_cfg<MODE, 4, 1, 2, 2, true>(p, s);
+        case 5: return launch_cfg<MODE, 2, 2, 1, 2, true>(p, s);
         default: return launch_cfg<MODE, 4, 1, 1, 1, true>(p, s);
       }
     }
@@ -446,6 +463,7 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
     case 1: return launch_cfg<MODE, 2, 2, 1, 1, false>(p, s);
     case 2: return launch_cfg<MODE, 4, 1, 2, 2, false>(p, s);
     case 4: return launch_cfg<MODE, 4, 1, 2, 4, false>(p, s);
+    case 5: return launch_cfg<MODE, 2, 2, 1, 2, false>(p, s);
     default: return launch_cfg<MODE, 4, 1, 1, 1, false>(p, s);
   }
 }

@@ -25,11 +25,31 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
-VARIANT_NAMES = {0: 'conv_direct_kernel', 1: 'thin_tconv_kernel', 100: 'conv_mfma<conv,128x128>', 101: 'conv_mfma<conv,64x64>',
-                 102: 'conv_mfma<conv,256x64>', 103: 'conv_mfma<conv,128x32>', 104: 'conv_mfma<conv,256x128>', 114: 'conv_mfma<tconv,256x128>', 124: 'conv_mfma<gdn,256x128>', 110: 'conv_mfma<tconv,128x128>',
-                 111: 'conv_mfma<tconv,64x64>', 112: 'conv_mfma<tconv,256x64>', 113: 'conv_mfma<tconv,128x32>',
-                 120: 'conv_mfma<gdn,128x128>', 121: 'conv_mfma<gdn,64x64>', 122: 'conv_mfma<gdn,256x64>',
-                 123: 'conv_mfma<gdn,128x32>'}
+_TILES = {0: '128x128', 1: '64x64', 2: '256x64', 3: '128x32', 4: '256x128', 5: '64x128'}
+_MODES = {0: 'conv', 1: 'tconv', 2: 'gdn'}
+
+
+def variant_name(v):
+    """aivc_conv2d_variant code -> readable kernel name"""
+    if v == 0:
+        return 'conv_direct_kernel'
+    if v == 1:
+        return 'thin_tconv_kernel'
+    c = v - 100
+    fused = c >= 50
+    c -= 50 if fused else 0
+    return 'conv_mfma<%s,%s%s>' % (_MODES.get(c // 10, '?'), _TILES.get(c % 10, '?'), '+gdn' if fused else '')
+
+
+class _Names(dict):
+    def get(self, k, default=None):
+        return variant_name(k)
+
+    def __contains__(self, k):
+        return True
+
+
+VARIANT_NAMES = _Names()
 
 
 def gpu_synthetic_unit(width, height, n_frames, t0, device, seed):
@@ -189,9 +209,6 @@ def main():
             d[1] += flops
             d[2] += e0.elapsed_time(e1) * 1e-3
         ops.PROFILE = None
-        for v in list(per):
-            if v >= 150 and (v - 50) in VARIANT_NAMES and v not in VARIANT_NAMES:
-                VARIANT_NAMES[v] = VARIANT_NAMES[v - 50].replace('>', '+gdn>')
         mf = {v: d for v, d in per.items() if v >= 100}
         if mf:
             dom = max(mf, key=lambda v: mf[v][2])
