@@ -19,7 +19,14 @@ FRAME_I, FRAME_P, FRAME_B = abi.FRAME_I, abi.FRAME_P, abi.FRAME_B
 PROFILE = None
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    # hipStream_t of torch's current stream on the current device (the raw getter avoids ~7 us of
+    # Python per launch)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -331,6 +338,25 @@ def table_bounds(table, q):
     return bounds
 
 
+_STAGING = []  # [(event or None, pinned uint8 tensor)]
+
+
+def _pinned_staging(n):
+    """pinned host buffer of >= n bytes whose previous H2D copy (if any) has completed"""
+    for i, (ev, buf) in enumerate(_STAGING):
+        if buf.numel() >= n and (ev is None or ev.query()):
+            _STAGING.pop(i)
+            return buf[:n]
+    return torch.empty(max(1 << 20, 1 << (int(n) - 1).bit_length()), dtype=torch.uint8, pin_memory=True)[:n]
+
+
+def _pinned_release(view):
+    ev = torch.cuda.Event()
+    ev.record()
+    base = view._base if view._base is not None else view
+    _STAGING.append((ev, base))
+
+
 def range_encode(bounds_list):
     """bounds_list: int32 CUDA tensors, one independent stream each (any number; launched 64 at a
     time, one wavefront per stream).  Returns (out uint8 tensor, lens int32 tensor [n], [(offset,
@@ -370,12 +396,15 @@ def range_decode(payloads, rows, row_offs, n_syms, planes):
     for pl in payloads:
         offs.append(total)
         total += len(pl) + (-len(pl)) % 4 + 8
-    host = torch.zeros(max(total, 4), dtype=torch.uint8)
+    host = _pinned_staging(max(total, 4))
     hv = host.numpy()
+    hv[:] = 0
     for pl, o in zip(payloads, offs):
         if len(pl):
             hv[o:o + len(pl)] = np.frombuffer(pl, np.uint8)
-    dbytes = host.to(dev, non_blocking=True)
+    dbytes = torch.empty(host.shape, dtype=torch.uint8, device=dev)
+    dbytes.copy_(host, non_blocking=True)  # pinned source: truly asynchronous, the host never waits
+    _pinned_release(host)
     sym_total = int(sum(n_syms))
     sym = torch.empty(max(sym_total, 1), dtype=torch.int16, device=dev)
     outs, so = [], 0

@@ -40,6 +40,40 @@ def split_sections(frame_bytes):
     return out
 
 
+_ROWS_WS = {}
+
+
+def _rows_workspace(n_rows, device):
+    """Caller-owned scratch for the decoder's CDF rows (1040 B per coded symbol): grown
+    monotonically and reused -- multi-GB allocations of varying size otherwise go back to hipMalloc
+    on every batch.  One buffer per (device, stream): the entropy stage runs on its own stream."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _ROWS_WS.get(key)
+    if ws is None or ws.shape[0] < n_rows:
+        ws = None
+        _ROWS_WS.pop(key, None)
+        ws = torch.empty((int(n_rows * 1.25) + 1024, abi.CDF_ROW), dtype=torch.int16, device=device)
+        _ROWS_WS[key] = ws
+    return ws[:n_rows]
+
+
+_PIN_POOL = {}
+
+
+def _pinned(n, dtype):
+    """pinned host staging buffer from a small free-list (hipHostMalloc per level is slow); the
+    buffer goes back to the pool when its EntropyJob has been collected"""
+    key = (dtype, max(1 << 16, 1 << (int(n) - 1).bit_length()))
+    lst = _PIN_POOL.setdefault(key, [])
+    t = lst.pop() if lst else torch.empty(key[1], dtype=dtype, pin_memory=True)
+    return t[:n]
+
+
+def _unpin(t):
+    base = t._base if t._base is not None else t
+    _PIN_POOL.setdefault((base.dtype, base.numel()), []).append(base)
+
+
 class EntropyJob:
     """Range-encode launches of a set of frames, possibly still running on a side stream."""
 
@@ -68,6 +102,10 @@ class EntropyJob:
                     blob += len(body).to_bytes(4, 'big') + body
             frames.append(blob)
         self.keep = None
+        if self.jobs:
+            _unpin(self.out_h)
+            _unpin(self.lens_h)
+            self.out_h = self.lens_h = None
         return frames
 
 
@@ -103,8 +141,8 @@ def launch_finalize(frames_sections, side_stream=None):
         keep = [frames_sections, bounds]
         if jobs:
             out, lens, offs = ops.range_encode(bounds)
-            out_h = torch.empty(out.shape, dtype=torch.uint8, pin_memory=True)
-            lens_h = torch.empty(lens.shape, dtype=torch.int32, pin_memory=True)
+            out_h = _pinned(out.numel(), torch.uint8)
+            lens_h = _pinned(lens.numel(), torch.int32)
             out_h.copy_(out, non_blocking=True)
             lens_h.copy_(lens, non_blocking=True)
             event = torch.cuda.Event()
@@ -175,7 +213,7 @@ class ArithmeticCoder():
         live = [i for i in range(n) if maps[i]]
         syms = {}
         if live:
-            rows = torch.empty((total, abi.CDF_ROW), dtype=torch.int16, device=sigma.device)
+            rows = _rows_workspace(total, sigma.device)
             for i in live:
                 ops.laplace_cdf_rows(sigma[i:i + 1], maps[i], out=rows, row_off=row_offs[i])
             dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], rows,
