@@ -41,8 +41,25 @@ class FrameCodec:
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def to444(planes):
-        return ops.yuv420_to_444(planes['y'], planes['u'], planes['v'], c_store=3)
+    def to444(planes, out=None, c_off=0):
+        """planar 4:2:0 -> 4 stored channels (y,u,v,0) of an NHWC tensor (a fresh [n,h,w,4] one, or
+        channels c_off..c_off+3 of `out`)"""
+        return ops.yuv420_to_444(planes['y'], planes['u'], planes['v'], c_store=4, c_off=c_off, out=out)
+
+    @staticmethod
+    def _images(parts, h, w, device):
+        """Concatenate 3-channel images, each padded to 4 stored channels, WITHOUT cat / pad kernels:
+        parts are plane dicts (converted in place), NHWC [n,h,w,4] tensors (copied into their slot) or
+        None (zeros).  The result carries the stored position of every real channel for the first conv."""
+        n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
+        buf = torch.zeros((n, h, w, 4 * len(parts)), dtype=torch.float32, device=device)
+        for i, p in enumerate(parts):
+            if isinstance(p, dict):
+                ops.yuv420_to_444(p['y'], p['u'], p['v'], c_off=4 * i, out=buf)
+            elif p is not None:
+                buf[..., 4 * i:4 * i + 4] = p
+        buf._aivc_cmap = tuple(4 * i + c for i in range(len(parts)) for c in range(3))
+        return buf
 
     def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
         """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts
@@ -50,24 +67,26 @@ class FrameCodec:
         -> list of {'bytes', 'rec', 'data_dim'[, 'aux']}"""
         n = len(cur)
         h, w = cur[0]['y'].shape[-2:]
-        code = self.to444(_stack(cur))
+        dev = cur[0]['y'].device
+        cur_p = _stack(cur)
         sections = [[None] * 4 for _ in range(n)]
         pred = skip = None
         aux = {}
         if frame_type != FRAME_I:
-            prev444 = self.to444(_stack(prev))
-            next444 = self.to444(_stack(nxt)) if frame_type == FRAME_B else torch.zeros_like(prev444)
-            a = self.mof.analyse(torch.cat((code, prev444, next444), dim=3), frame_type, idx_rate)
-            short_in = torch.cat((prev444, next444), dim=3) if frame_type == FRAME_B else None
+            prev_p = _stack(prev)
+            next_p = _stack(nxt) if frame_type == FRAME_B else None
+            prev444 = self.to444(prev_p)
+            next444 = self.to444(next_p) if next_p is not None else torch.zeros_like(prev444)
+            a = self.mof.analyse(self._images((cur_p, prev_p, next_p), h, w, dev), frame_type, idx_rate)
+            short_in = self._images((prev_p, next_p), h, w, dev) if frame_type == FRAME_B else None
             mof_out = self.mof.synthesise(a['y_hat'], short_in)
-            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3, want_aux=want_aux)
+            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=4, want_aux=want_aux)
             pred, skip = wb['pred'], wb['skip']
             for i, (sz, sy) in enumerate(zip(self.mof.ac.pend_z(a['q_z']), self.mof.ac.pend_y(a['q_y'], a['sigma']))):
                 sections[i][0], sections[i][1] = sz, sy
             if want_aux:
-                aux.update(alpha=wb['alpha'], beta=wb['beta'], warping=wb['x_warp'])
-        zero_pred = torch.zeros_like(code) if pred is None else pred
-        c = self.cod.analyse(torch.cat((code, zero_pred), dim=3), frame_type, idx_rate)
+                aux.update(alpha=wb['alpha'], beta=wb['beta'], warping=wb['x_warp'][..., :3])
+        c = self.cod.analyse(self._images((cur_p, pred), h, w, dev), frame_type, idx_rate)
         cod_out = self.cod.synthesise(c['y_hat'], pred)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         for i, (sz, sy) in enumerate(zip(self.cod.ac.pend_z(c['q_z']), self.cod.ac.pend_y(c['q_y'], c['sigma']))):
@@ -76,7 +95,7 @@ class FrameCodec:
                     'x_uv': (math.ceil(h / 2), math.ceil(w / 2))}
         recs = _unstack(dict(zip('yuv', rec8)), n)
         if want_aux:
-            aux['code'] = code
+            aux['code'] = ops.yuv420_to_444(cur_p['y'], cur_p['u'], cur_p['v'], c_store=3)
         return {'sections': sections, 'rec': recs, 'data_dim': data_dim, 'aux': aux}
 
     def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
@@ -112,11 +131,13 @@ class FrameCodec:
         n = y_hats['cod'].shape[0]
         pred = skip = None
         if frame_type != FRAME_I:
-            prev444 = self.to444(_stack(prev))
-            next444 = self.to444(_stack(nxt)) if frame_type == FRAME_B else torch.zeros_like(prev444)
-            short_in = torch.cat((prev444, next444), dim=3) if frame_type == FRAME_B else None
+            prev_p = _stack(prev)
+            next_p = _stack(nxt) if frame_type == FRAME_B else None
+            prev444 = self.to444(prev_p)
+            next444 = self.to444(next_p) if next_p is not None else torch.zeros_like(prev444)
+            short_in = self._images((prev_p, next_p), h, w, prev444.device) if frame_type == FRAME_B else None
             mof_out = self.mof.synthesise(y_hats['mof'], short_in)
-            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=3)
+            wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=4)
             pred, skip = wb['pred'], wb['skip']
         cod_out = self.cod.synthesise(y_hats['cod'], pred)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)

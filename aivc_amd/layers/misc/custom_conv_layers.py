@@ -36,23 +36,28 @@ def _sq(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def packed_conv(conv, c_store, device):
-    """(OHWI weight, bias) of a Conv2d / ConvTranspose2d on `device`, input channels padded to c_store."""
+def packed_conv(conv, c_store, device, cmap=None):
+    """(OHWI weight, bias) of a Conv2d / ConvTranspose2d on `device`, input channels padded to c_store.
+    cmap: stored position of every real input channel (default: the first ones) -- lets a caller feed
+    images whose 3-channel planes are each padded to 4 ([y,u,v,0, y,u,v,0, ...]) without a repack."""
     transposed = isinstance(conv, ConvTranspose2d)
 
     def build():
-        w = ops.pack_weight(conv.weight.to(device, torch.float32), c_store, transposed=transposed)
+        w = ops.pack_weight(conv.weight.to(device, torch.float32), None, transposed=transposed)
+        ci = w.shape[3]
+        wp = torch.zeros(w.shape[:3] + (c_store,), dtype=torch.float32, device=device)
+        wp[..., list(cmap) if cmap is not None else slice(0, ci)] = w
         b = None if conv.bias is None else conv.bias.detach().to(device, torch.float32).contiguous()
-        return w, b
+        return wp.contiguous(), b
     params = (conv.weight,) if conv.bias is None else (conv.weight, conv.bias)
-    return cached(conv, ('w', c_store, str(device)), params, build)
+    return cached(conv, ('w', c_store, str(device), None if cmap is None else tuple(cmap)), params, build)
 
 
 def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=None, gdn=None):
     """x NHWC -> NHWC through one aivc_conv2d launch for a torch Conv2d / ConvTranspose2d.
     gdn: optional GDN module applied to the conv output (fused into the epilogue when possible)."""
     c_store = (x.shape[-1] + 3) // 4 * 4
-    w, b = packed_conv(conv, c_store, x.device)
+    w, b = packed_conv(conv, c_store, x.device, getattr(x, '_aivc_cmap', None))
     g = None
     if gdn is not None:
         if gdn.beta.shape[0] % 4:  # exotic channel count: padded stand-alone path
