@@ -220,3 +220,16 @@ def test_reference_style_api_round_trip(cuda, tmp_path):
                       'device': 'cuda:0'})
     assert torch.equal((rec['y'] * 255).round().to(torch.uint8)[0], got[0]['y'])
     np.testing.assert_array_equal(raw[:64 * 48].reshape(48, 64), got[0]['y'][0].cpu().numpy())
+
+
+def test_level_sharded_entry_point_single_rank(cuda):
+    """parallel.encode_units_level_sharded with world_size 1 == FrameCodec.encode_units (the 2-rank
+    case runs on gloo in tests/test_multi_process.py)"""
+    from aivc_amd import parallel
+    model, frames, dframes = _setup(cuda, 64, 48, 10, seed=8)
+    fc = model.frame_codec()
+    units = [dframes[:5], dframes[5:]]
+    with torch.no_grad():
+        ref, _, dd = fc.encode_units(units, '1_GOP_4')
+        got, dd2 = parallel.encode_units_level_sharded(fc, units, '1_GOP_4')
+    assert got == ref and dd2['y'] == dd['y']

@@ -86,3 +86,66 @@ def test_two_rank_sharding_matches_single_process(oracle):
     model = synth.make_model(arch.TINY_WIDTHS, seed=100)
     ref, _ = oc.encode_video(ospec.export_model(model), synth.synthetic_video(48, 32, 7, seed=2), 'LDP_2')
     assert blobs[0] == ref
+
+
+class OracleFrameCodec:
+    """encode_batch / max_batch look-alike of aivc_amd.codec.FrameCodec on the CPU oracle, returning
+    ready frame bytes through a one-element 'sections' wrapper understood by finalize_frames' stub."""
+    max_batch = 4
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0.):
+        from oracle import codec as oc
+        recs, secs, dd = [], [], None
+
+        def np_planes(p):
+            return None if p is None else {k: p[k][0].numpy() for k in 'yuv'}
+        for c, p, n in zip(cur, prev, nxt):
+            fb, rec, dd = oc.encode_frame(self.spec, np_planes(c), np_planes(p), np_planes(n), frame_type, idx_rate)
+            recs.append({k: torch.from_numpy(rec[k]).unsqueeze(0) for k in 'yuv'})
+            secs.append(fb)
+        return {'sections': secs, 'rec': recs, 'data_dim': dict(dd, x_uv=None)}
+
+
+def _worker_levels(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import aivc_amd.real_life.bitstream as bs
+    bs.finalize_frames = lambda secs: list(secs)  # the oracle codec already returns frame bytes
+    from aivc_amd import parallel, synth
+    from aivc_amd.models import arch
+    from oracle import spec as ospec
+    model = synth.make_model(arch.TINY_WIDTHS, seed=100)
+    frames = synth.synthetic_video(48, 32, 10, seed=2)
+    units = [[{k: torch.from_numpy(f[k]).unsqueeze(0) for k in 'yuv'} for f in frames[u * 5:u * 5 + 5]] for u in range(2)]
+    blobs, dd = parallel.encode_units_level_sharded(OracleFrameCodec(ospec.export_model(model)), units, '1_GOP_4')
+    q.put((rank, blobs, dd['x'], dd['y'], dd['z']))
+    dist.destroy_process_group()
+
+
+def test_temporal_level_sharding_matches_single_process(oracle):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_levels, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]  # every rank ends with the same GOP records
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from oracle import codec as oc
+    from oracle import spec as ospec
+    model = synth.make_model(arch.TINY_WIDTHS, seed=100)
+    ref, _ = oc.encode_video(ospec.export_model(model), synth.synthetic_video(48, 32, 10, seed=2), '1_GOP_4')
+    assert oc.split_lp(ref, 18, 2) == res[0][1]
+    assert (res[0][2], res[0][3], res[0][4]) == ((32, 48), tuple(int.from_bytes(ref[i:i + 2], 'big') for i in (4, 6)),
+                                                  tuple(int.from_bytes(ref[i:i + 2], 'big') for i in (8, 10)))
