@@ -82,6 +82,7 @@ class FrameCodec:
             mof_out = self.mof.synthesise(a['y_hat'], short_in)
             wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=4, want_aux=want_aux)
             pred, skip = wb['pred'], wb['skip']
+            pred._aivc_cmap = (0, 1, 2)  # 3 real channels + a zero pad channel
             for i, (sz, sy) in enumerate(zip(self.mof.ac.pend_z(a['q_z']), self.mof.ac.pend_y(a['q_y'], a['sigma']))):
                 sections[i][0], sections[i][1] = sz, sy
             if want_aux:
@@ -139,6 +140,7 @@ class FrameCodec:
             mof_out = self.mof.synthesise(y_hats['mof'], short_in)
             wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=4)
             pred, skip = wb['pred'], wb['skip']
+            pred._aivc_cmap = (0, 1, 2)
         cod_out = self.cod.synthesise(y_hats['cod'], pred)
         _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         return _unstack(dict(zip('yuv', rec8)), n)

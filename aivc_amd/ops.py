@@ -90,7 +90,8 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     bit-identical either way."""
     x = _dev(x, torch.float32, 'x')
     n, h, w_, c = x.shape
-    c_real = c
+    cmap = getattr(x, '_aivc_cmap', None)
+    c_real = c if cmap is None else len(cmap)  # algorithmic FLOPs count real channels, not zero padding
     if c % 4:
         x = pad_channels(x, (c + 3) // 4 * 4)
         c = x.shape[-1]
