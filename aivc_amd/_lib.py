@@ -7,7 +7,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libaivc_hip.so')
+# AIVC_HIP_LIB: kernel-tuning aid (tools/), points at an alternative build of the same HIP library
+LIB_PATH = os.environ.get('AIVC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libaivc_hip.so')
 
 _lib = None
 _fns = None

@@ -14,7 +14,7 @@
 //                  lane half h = lane>>5 of the MFMA needs k = 2j + h, so one ds_read_b128 at
 //                  column 8*o + 4*h yields its operand for 4 consecutive MFMA steps.
 //   im2col         done in the loader's address arithmetic: replicate padding = clamp of the input
-//                  coordinate; transposed conv = 4 output-parity classes (blockIdx.z), each a small
+//                  coordinate; transposed conv = 4 output-parity classes (slowest tile index), each a small
 //                  dense conv over the taps of that parity with zero fill outside the image.
 //   epilogue       bias / GDN division / activation / gate / residual fused, straight from the
 //                  accumulators (lanes 0-31 of a row write 128 contiguous bytes).
@@ -30,34 +30,65 @@ struct MfmaArgs {
   aivc_conv_params p;
   int M;               // GEMM rows per z-slice
   uint32_t cin_magic;  // ceil(2^32 / c_in): k / c_in == (k * magic) >> 32 for k < 2^16
+  uint32_t w_magic, h_magic;  // floor(2^32 / w_in), floor(2^32 / h_in): quotient low by at most one
+  int gx, gy;                  // pixel tiles, c_out tiles (the grid is 1-D: gx x gy x parity classes)
 };
 
 constexpr int BK = 32;
+constexpr int OCT = BK / 8;  // 8-float units per LDS row
 constexpr int LDS_STRIDE = BK + 4;
+
+#ifdef AIVC_PHASE_TIMING
+__device__ unsigned long long aivc_dbg_t[8 * 8192];
+#define DBG_T(i) if (threadIdx.x == 0 && blockIdx.x < 8192) aivc_dbg_t[blockIdx.x * 8 + (i)] = (i) == 0 || (i) == 5 ? wall_clock64() : clock64()
+#else
+#define DBG_T(i)
+#endif
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
 __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-  constexpr int UA = BM * 4 / 256;          // (row, octet) units per thread for A
-  constexpr int UB = (BN * 4 + 255) / 256;  // ... for B
+  constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
+  constexpr int UB = (BN * OCT + 255) / 256;  // ... for B
   constexpr bool TCONV = MODE == AIVC_MODE_TCONV;
   constexpr bool GDN = MODE == AIVC_MODE_GDN;  // covers IGDN (runtime mode in the epilogue)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  DBG_T(0);
+  DBG_T(1);
+#ifdef AIVC_PHASE_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 8192) aivc_dbg_t[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
   float *As = smem;
   float *Bs = smem + BM * LDS_STRIDE;
 
   const aivc_conv_params &p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order (stride-1/2 conv and GDN).  The dispatcher deals consecutive workgroup ids
+  // round-robin to the 8 XCDs (each with a private 4 MiB L2); remap (bijectively) so that one XCD works on
+  // a contiguous run of tiles, ordered so that neighbours share input: the c_out tiles of one pixel tile
+  // first (same A rows), then the next pixel tile (shared halo rows).
+  // Transposed conv keeps the dispatch order, parity class slowest: its 4 classes have reductions of
+  // different length (9/6/6/4 taps for k = 5), so contiguous runs per XCD unbalance the XCDs, and
+  // interleaving the classes instead measured 25% slower as well (tools/bench_conv.py).
+  uint32_t tile_id = blockIdx.x;
+  if (MODE != AIVC_MODE_TCONV) {
+    const uint32_t nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const uint32_t per_class = (uint32_t)a.gx * (uint32_t)a.gy;
+  const int bz = MODE == AIVC_MODE_TCONV ? (int)(tile_id / per_class) : 0;
+  if (MODE == AIVC_MODE_TCONV) tile_id -= (uint32_t)bz * per_class;
+  const int by = (int)(tile_id % (uint32_t)a.gy), bx = (int)(tile_id / (uint32_t)a.gy);
+  const int m0 = bx * BM, n0 = by * BN;
   const int ks = p.ksize, Cin = p.c_in, H = p.h_in, W = p.w_in, Cout = p.c_out;
   const int M = a.M;
 
   int pyc = 0, pxc = 0, ky0 = 0, kx0 = 0, nky = ks, nkx = ks, tpad = 0;
   if (TCONV) {
     tpad = (ks + 1) / 2 - 1;
-    pyc = blockIdx.z >> 1;
-    pxc = blockIdx.z & 1;
+    pyc = bz >> 1;
+    pxc = bz & 1;
     ky0 = (pyc + tpad) & 1;
     kx0 = (pxc + tpad) & 1;
     nky = (ks - ky0 + 1) / 2;
@@ -72,7 +103,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   uint32_t a_nb[UA];
 #pragma unroll
   for (int j = 0; j < UA; ++j) {
-    const int row = (tid + 256 * j) >> 2;
+    const int row = (tid + 256 * j) / OCT;
     int m = m0 + row;
     m = m < M ? m : M - 1;
     if (TCONV) {
@@ -105,11 +136,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
   for (int j = 0; j < UB; ++j) {
     const int u = tid + 256 * j;
-    const int co = n0 + (u >> 2);
-    b_ok[j] = u < BN * 4;
+    const int co = n0 + u / OCT;
+    b_ok[j] = u < BN * OCT;
     const int coc = co < Cout ? co : Cout - 1;  // clamped: rows beyond c_out are never stored
-    b_off[j] = TCONV ? (uint32_t)coc * (uint32_t)(ks * ks * Cin) + (uint32_t)((u & 3) * 8)
-                     : (uint32_t)coc * (uint32_t)K + (uint32_t)((u & 3) * 8);
+    b_off[j] = TCONV ? (uint32_t)coc * (uint32_t)(ks * ks * Cin) + (uint32_t)((u % OCT) * 8)
+                     : (uint32_t)coc * (uint32_t)K + (uint32_t)((u % OCT) * 8);
   }
   auto load_tile_fast = [&](int kt) {
     const int kbase = kt * BK;
@@ -123,7 +154,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       if (TCONV) ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
       iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
       ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
-      const float *src = p.x + ((a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(ci0 + ((tid + 256 * j) & 3) * 8));
+      const float *src = p.x + ((a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(ci0 + ((tid + 256 * j) % OCT) * 8));
       float4 v0 = *reinterpret_cast<const float4 *>(src);
       float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
       if (TCONV) {
@@ -156,7 +187,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     const int kbase = kt * BK;
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
-      const int oct = (tid + 256 * j) & 3;
+      const int oct = (tid + 256 * j) % OCT;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int kk = kbase + oct * 8 + q * 4;
@@ -190,8 +221,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const int u = tid + 256 * j;
-      const int oct = u & 3;
-      const int co = n0 + (u >> 2);
+      const int oct = u % OCT;
+      const int co = n0 + u / OCT;
       const int coc = co < Cout ? co : Cout - 1;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -217,19 +248,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     else load_tile_generic(kt);
   };
 
-  auto store_tile = [&]() {
+  auto store_tile_a = [&]() {
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
       const int u = tid + 256 * j;
-      float *dst = As + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
+      float *dst = As + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
       *reinterpret_cast<float4 *>(dst) = make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z);
       *reinterpret_cast<float4 *>(dst + 4) = make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w);
     }
+  };
+  auto store_tile_b = [&]() {
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const int u = tid + 256 * j;
-      if (u < BN * 4) {
-        float *dst = Bs + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
+      if (u < BN * OCT) {
+        float *dst = Bs + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
         *reinterpret_cast<float4 *>(dst) = make_float4(rb[j][0].x, rb[j][0].z, rb[j][1].x, rb[j][1].z);
         *reinterpret_cast<float4 *>(dst + 4) = make_float4(rb[j][0].y, rb[j][0].w, rb[j][1].y, rb[j][1].w);
       }
@@ -247,14 +280,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   const float *a_frag = As + (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
   const float *b_frag = Bs + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
 
-  load_tile(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  // one K-tile of MFMAs out of LDS (measured in isolation, tools/mfma_probe.hip: this loop keeps the
+  // matrix pipe 98% busy, i.e. what is lost in the whole kernel is lost outside of it)
+  auto mma_tile = [&](floatx16 (&c)[TM][TN]) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < OCT; ++o) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
@@ -268,19 +298,44 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c[i][j], 0, 0, 0);
           }
         }
       }
     }
+  };
+
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt == 1) { DBG_T(2); }
+    __syncthreads();
+    store_tile_a();
+    store_tile_b();
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    mma_tile(acc);
   }
 
   // ---- fused (I)GDN: second, small GEMM  s[m][i] = sum_j x[m][j]^2 * gamma[i][j]  -------------
   // The biased conv outputs x stay in `acc`; their squares go through LDS (the A tile buffer) one
   // 32-channel chunk at a time, gamma streams through the B tile buffer.  BN == c_out here, so a
   // workgroup owns every channel of its pixels.
+  DBG_T(3);
   floatx16 acc2[FUSE ? TM : 1][FUSE ? TN : 1];
   if constexpr (FUSE) {
+    // gamma chunk kt2 -> registers (the weight staging registers are free now), one chunk ahead of its use
+    auto load_gamma = [&](int kt2) {
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int u = tid + 256 * j;
+        if (u < BN * OCT) {
+          const float *src = p.gdn_gamma + (size_t)(u / OCT) * Cout + kt2 * BK + (u % OCT) * 8;
+          rb[j][0] = *reinterpret_cast<const float4 *>(src);
+          rb[j][1] = *reinterpret_cast<const float4 *>(src + 4);
+        }
+      }
+    };
+    load_gamma(0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int co = (wn * TN + j) * 32 + (lane & 31);
@@ -295,85 +350,150 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     }
     const int k_in = lane & 31;
     const int pos = (k_in >> 3) * 8 + (k_in & 1) * 4 + ((k_in & 7) >> 1);  // even ks first inside an octet
-    for (int kt2 = 0; kt2 < Cout / BK; ++kt2) {
+    constexpr int NB = BK / 32;  // 32-channel accumulator blocks per K chunk
+    const int nk2 = Cout / BK;
+    for (int kt2 = 0; kt2 < nk2; ++kt2) {
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (wn * TN + j == kt2) {
+        const int blk = wn * TN + j - kt2 * NB;
+        if (blk >= 0 && blk < NB) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
               const float xv = acc[i][j][r];
-              As[row * LDS_STRIDE + pos] = xv * xv;
+              As[row * LDS_STRIDE + blk * 32 + pos] = xv * xv;
             }
         }
       }
-#pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        const int u = tid + 256 * j;
-        if (u < BN * 4) {
-          const float *src = p.gdn_gamma + (size_t)(u >> 2) * Cout + kt2 * BK + (u & 3) * 8;
-          const float4 q0 = *reinterpret_cast<const float4 *>(src);
-          const float4 q1 = *reinterpret_cast<const float4 *>(src + 4);
-          float *dst = Bs + (u >> 2) * LDS_STRIDE + (u & 3) * 8;
-          *reinterpret_cast<float4 *>(dst) = make_float4(q0.x, q0.z, q1.x, q1.z);
-          *reinterpret_cast<float4 *>(dst + 4) = make_float4(q0.y, q0.w, q1.y, q1.w);
-        }
-      }
+      store_tile_b();
       __syncthreads();
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        float4 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + j * 32 * LDS_STRIDE + o * 8);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float av = s == 0 ? af[i].x : (s == 1 ? af[i].y : (s == 2 ? af[i].z : af[i].w));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
-              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
-            }
-          }
-        }
-      }
+      if (kt2 + 1 < nk2) load_gamma(kt2 + 1);
+      mma_tile(acc2);
     }
   }
 
+  DBG_T(4);
   // ---- epilogue ---------------------------------------------------------------------------
-  Epilogue ep{p.bias, p.mul, p.res, p.x, p.y, p.act1, p.act2, p.mode};
+  // Same arithmetic and order as Epilogue::store/finish (common.h), organised for the instruction cache:
+  // the unrolled per-accumulator code holds only branch-free work (bias, GDN division, leaky/relu as a
+  // select, gate, residual); the sigmoid activation (an fp64 polynomial, include/aivc_detmath.h) would be
+  // inlined 128 times there -- 150 KB of code that even when skipped made every output an instruction
+  // cache miss and stretched the epilogue to a fifth of the kernel.  Layers that use it (attention gates)
+  // store the pre-activation value and finish in a rolled second pass over the thread's own outputs.
+  // Per-channel constants are read once; per-pixel operands of 4 rows are fetched before those rows are
+  // stored so no load queues behind a store.
+  {
+    const float *__restrict__ g_mul = p.mul;
+    const float *__restrict__ g_res = p.res;
+    const float *__restrict__ g_x = p.x;
+    float *__restrict__ g_y = p.y;
+    const int act1 = p.act1, act2 = p.act2;
+    const bool heavy = act1 == AIVC_ACT_SIGMOID || act2 == AIVC_ACT_SIGMOID;
+    const bool has_bias = p.bias != nullptr, has_mul = p.mul != nullptr && !heavy, has_res = p.res != nullptr && !heavy;
+    const bool gdn_mode = GDN;  // stand-alone (I)GDN launch: normalise the input by the accumulator
+    auto act_cheap = [](int act, float v) {  // NONE / LEAKY / RELU of act_apply() without branches
+      const float neg = act == AIVC_ACT_LEAKY ? v * 0.01f : (act == AIVC_ACT_RELU ? 0.0f : v);
+      return v > 0.0f ? v : neg;
+    };
+    auto out_pixel = [&](uint32_t mc) -> size_t {
+      if (!TCONV) return (size_t)mc;
+      uint32_t t = __umulhi(mc, a.w_magic), qx = mc - t * (uint32_t)W;
+      if (qx >= (uint32_t)W) { ++t; qx -= (uint32_t)W; }
+      uint32_t n = __umulhi(t, a.h_magic), qy = t - n * (uint32_t)H;
+      if (qy >= (uint32_t)H) { ++n; qy -= (uint32_t)H; }
+      return ((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc);
+    };
+    float cb[TN], cbeta[TN];
+    int cch[TN];
+    bool cok[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
+      cok[j] = co < Cout;
+      cch[j] = cok[j] ? co : Cout - 1;
+      cb[j] = (!FUSE && has_bias) ? p.bias[cch[j]] : 0.0f;
+      cbeta[j] = FUSE ? p.gdn_beta[cch[j]] : 0.0f;
+    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= M) continue;
-      size_t opix = (size_t)m;
-      if (TCONV) {
-        const int qx = m % W, t = m / W;
-        const int qy = t % H, n = t / H;
-        opix = ((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc);
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        size_t base[4];
+        bool ok[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int m = m0 + (wm * TM + i) * 32 + rr + 8 * rg + 4 * (lane >> 5);
+          ok[rr] = m < M;
+          base[rr] = out_pixel((uint32_t)(ok[rr] ? m : M - 1)) * (size_t)Cout;
+        }
+        float vm[4][TN], vr[4][TN], vx[4][TN];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const size_t o = base[rr] + cch[j];
+            vm[rr][j] = has_mul ? g_mul[o] : 1.0f;
+            vr[rr][j] = has_res ? g_res[o] : 0.0f;
+            vx[rr][j] = gdn_mode ? g_x[o] : 0.0f;
+          }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int r = rg * 4 + rr;
+            float v;
+            if constexpr (FUSE) {
+              const float nrm = __builtin_sqrtf(acc2[i][j][r] + cbeta[j]);
+              const float xv = acc[i][j][r];
+              v = p.gdn == 2 ? xv * nrm : xv / nrm;
+            } else {
+              v = acc[i][j][r];
+              if (has_bias) v = v + cb[j];
+              if (gdn_mode) {
+                const float nrm = __builtin_sqrtf(v);
+                v = p.mode == AIVC_MODE_IGDN ? vx[rr][j] * nrm : vx[rr][j] / nrm;
+              }
+            }
+            if (!heavy) {
+              v = act_cheap(act1, v);
+              if (has_mul) v = vm[rr][j] * v;
+              if (has_res) v = v + vr[rr][j];
+              v = act_cheap(act2, v);
+            }
+            if (ok[rr] && cok[j]) g_y[base[rr] + cch[j]] = v;
+          }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
+    }
+    if (heavy) {
+      __threadfence_block();  // the pass below re-reads this thread's own stores
+      float *y2 = p.y;
+#pragma unroll 1
+      for (int q = 0; q < TM * 16 * TN; ++q) {
+        const int j = q % TN, r = (q / TN) & 15, i = q / (TN * 16);
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if constexpr (FUSE) {
-          const float nrm = __builtin_sqrtf(acc2[i][j][r] + p.gdn_beta[co]);
-          const float xv = acc[i][j][r];
-          ep.finish(opix, co, Cout, p.gdn == 2 ? xv * nrm : xv / nrm);
-        } else {
-          if (co < Cout) ep.store(opix, co, Cout, acc[i][j][r]);
+        if (m < M && co < Cout) {
+          const size_t o = out_pixel((uint32_t)m) * (size_t)Cout + co;
+          float v = act_apply(act1, y2[o]);
+          if (p.mul) v = p.mul[o] * v;
+          if (p.res) v = v + p.res[o];
+          y2[o] = act_apply(act2, v);
         }
       }
     }
   }
+  DBG_T(6);
+  DBG_T(5);
 }
+
+#ifdef AIVC_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int aivc_dbg_dump(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(aivc_dbg_t), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
 static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
@@ -382,7 +502,11 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   a.p = p;
   a.M = MODE == AIVC_MODE_TCONV ? p.n * p.h_in * p.w_in : p.n * p.h_out * p.w_out;
   a.cin_magic = (uint32_t)((0x100000000ull + (uint64_t)p.c_in - 1) / (uint64_t)p.c_in);
-  dim3 grid((a.M + BM - 1) / BM, (p.c_out + BN - 1) / BN, MODE == AIVC_MODE_TCONV ? 4 : 1);
+  a.w_magic = p.w_in > 1 ? (uint32_t)(0x100000000ull / (uint64_t)p.w_in) : 0xFFFFFFFFu;
+  a.h_magic = p.h_in > 1 ? (uint32_t)(0x100000000ull / (uint64_t)p.h_in) : 0xFFFFFFFFu;
+  a.gx = (a.M + BM - 1) / BM;
+  a.gy = (p.c_out + BN - 1) / BN;
+  dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
   const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");

@@ -24,8 +24,31 @@ SHAPES = [  # name, mode, k, s, pad, cin, cout, h_in, w_in
 ]
 
 
+def clock_probe():
+    """Optional (CLOCK=1): side-stream spin kernel reporting the shader clock during the timed launches."""
+    import ctypes, subprocess
+    so = '/tmp/libclock_probe.so'
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'clock_probe.hip')
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O2', '-shared', '-fPIC', '-w', src, '-o', so])
+    lib = ctypes.CDLL(so)
+    lib.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    side = torch.cuda.Stream()
+    buf = torch.zeros(2, dtype=torch.int64, device='cuda:0')
+
+    def start(us):
+        side.wait_stream(torch.cuda.current_stream())
+        lib.clock_probe_launch(buf.data_ptr(), float(us), side.cuda_stream)
+
+    def read():
+        side.synchronize()
+        c, r = buf.tolist()
+        return c / max(r, 1) * 0.1  # GHz (s_memrealtime = 100 MHz)
+    return start, read
+
+
 def main():
     dev = torch.device('cuda:0')
+    clk = clock_probe() if os.environ.get('CLOCK') else None
     nb = int(os.environ.get('BATCH', '1'))
     tot_f, tot_t = 0.0, 0.0
     for name, mode, k, s, pad, ci, co, h, w in SHAPES:
@@ -47,13 +70,17 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = 5
+            if clk:
+                n = 20
+                clk[0](1500.0)
             e0.record()
             for _ in range(n):
                 ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo, gdn=g)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
-            print('%-32s algo=%d %s %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, '+gdn' if g is not None else '    ', ms, fl / 1e9, fl / ms / 1e9))
+            print('%-32s algo=%d %s %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, '+gdn' if g is not None else '    ', ms, fl / 1e9, fl / ms / 1e9)
+                  + ('  clk %.3f GHz' % clk[1]() if clk else ''))
         tot_f += flops
         tot_t += ms
     print('sum: %.1f GFLOP in %.2f ms -> %.1f TFLOP/s' % (tot_f / 1e9, tot_t, tot_f / tot_t / 1e9))

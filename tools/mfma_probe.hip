@@ -1,0 +1,253 @@
+// Stand-alone probe (not part of the product library):
+//  1. sustained fp32 MFMA rate of this box with no memory traffic (the practical ceiling the
+//     conv kernels are priced against next to the 157.3 TFLOP/s data-sheet peak);
+//  2. whether v_mfma_f32_16x16x4_f32 accumulates k = 0..3 as one ordered fmaf chain, the property
+//     conv_mfma.hip relies on for v_mfma_f32_32x32x2_f32.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/mfma_probe.hip -o gpurun_out/mfma_probe
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int K>
+__global__ __launch_bounds__(256) void peak32(float* out, int iters, float a, float b) {
+    f16v acc[K];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Same loop with data-dependent operands (random mantissas, rotated every step) so the datapath toggles as
+// it does in a real convolution: separates "issue-limited" from "power/clock-limited".
+__global__ __launch_bounds__(256) void peak32_rand(float* out, const float* in, int iters) {
+    f16v acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float a[8], b[8];
+    for (int i = 0; i < 8; ++i) {
+        a[i] = in[(threadIdx.x * 8 + i) & 4095];
+        b[i] = in[(threadIdx.x * 8 + i + 2048) & 4095];
+    }
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 + i], b[4 + i], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// The conv kernel's inner loop in isolation: operands come from LDS with the same row stride / fragment
+// addressing (ds_read_b128 per 4 MFMA steps), 2x2 accumulator blocks per wave, no barriers, no global loads.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <bool PIPE>
+__global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in, int iters) {
+    constexpr int STRIDE = 36;
+    __shared__ __attribute__((aligned(16))) float smem[256 * STRIDE];
+    for (int i = threadIdx.x; i < 256 * STRIDE; i += 256) smem[i] = in[i & 4095];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* a_frag = smem + (wm * 64 + (lane & 31)) * STRIDE + (lane >> 5) * 4;
+    const float* b_frag = smem + 128 * STRIDE + (wn * 64 + (lane & 31)) * STRIDE + (lane >> 5) * 4;
+    f16v acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            f4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f4*>(a_frag + i * 32 * STRIDE + o * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f4*>(b_frag + j * 32 * STRIDE + o * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void peak16(float* out, int iters, float a, float b) {
+    f4v acc[K];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// One wave: D = A(16x4) * B(4x16) + C through one 16x16x4 instruction, `steps` times with fresh A/B.
+__global__ void order16(const float* A, const float* B, const float* C, float* D, int steps) {
+    const int l = threadIdx.x;
+    f4v acc;
+    for (int r = 0; r < 4; ++r) acc[r] = C[(4 * (l / 16) + r) * 16 + (l % 16)];
+    for (int s = 0; s < steps; ++s) {
+        const float a = A[s * 64 + (l % 16) * 4 + (l / 16)];   // A[i][k], i = l%16, k = l/16
+        const float b = B[s * 64 + (l / 16) * 16 + (l % 16)];  // B[k][j], k = l/16, j = l%16
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) D[(4 * (l / 16) + r) * 16 + (l % 16)] = acc[r];
+}
+
+static float rnd_wide() {
+    const float m = (float)rand() / RAND_MAX * 2.f - 1.f;
+    const int e = rand() % 24 - 12;
+    return ldexpf(m, e);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d", prop.gcnArchName, cus, prop.clockRate / 1000);
+    float* out;
+    hipMalloc(&out, sizeof(float) * 256 * cus * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 20000;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int wpc = 1; wpc <= 2; ++wpc) {  // workgroups of 4 waves per CU
+            float ms;
+            hipLaunchKernelGGL(peak32<4>, dim3(cus * wpc), dim3(256), 0, 0, out, 100, 1.f, 1.f);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(peak32<4>, dim3(cus * wpc), dim3(256), 0, 0, out, iters, 1.f, 1e-9f);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            double fl = 2.0 * 32 * 32 * 2 * 4.0 * iters * 4.0 * cus * wpc;
+            if (pass) printf(", \"mfma32x32x2_f32_tflops_wg%d\": %.1f", wpc, fl / ms * 1e-9);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(peak16<4>, dim3(cus * wpc), dim3(256), 0, 0, out, iters, 1.f, 1e-9f);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            fl = 2.0 * 16 * 16 * 4 * 4.0 * iters * 4.0 * cus * wpc;
+            if (pass) printf(", \"mfma16x16x4_f32_tflops_wg%d\": %.1f", wpc, fl / ms * 1e-9);
+        }
+    }
+    // long run (about 2 s) to see the sustained, power-managed clock
+    {
+        float ms;
+        hipEventRecord(e0);
+        for (int r = 0; r < 40; ++r)
+            hipLaunchKernelGGL(peak32<4>, dim3(cus * 2), dim3(256), 0, 0, out, iters * 4, 1.f, 1e-9f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 40.0 * 2.0 * 32 * 32 * 2 * 4.0 * iters * 4 * 4.0 * cus * 2;
+        printf(", \"mfma32x32x2_f32_tflops_sustained\": %.1f, \"sustained_s\": %.2f", fl / ms * 1e-9, ms * 1e-3);
+    }
+
+    {
+        std::vector<float> h(4096);
+        srand(3);
+        for (auto& v : h) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 1e-3f;
+        float* din;
+        hipMalloc(&din, 4096 * 4);
+        hipMemcpy(din, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+        float ms;
+        hipLaunchKernelGGL(peak32_rand, dim3(cus * 2), dim3(256), 0, 0, out, din, 100);
+        hipEventRecord(e0);
+        for (int r = 0; r < 40; ++r)
+            hipLaunchKernelGGL(peak32_rand, dim3(cus * 2), dim3(256), 0, 0, out, din, iters * 4);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 40.0 * 2.0 * 32 * 32 * 2 * 4.0 * iters * 4 * 4.0 * cus * 2;
+        printf(", \"mfma32x32x2_f32_tflops_random_operands\": %.1f, \"random_s\": %.2f", fl / ms * 1e-9, ms * 1e-3);
+    }
+    {
+        std::vector<float> h(4096);
+        srand(5);
+        for (auto& v : h) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
+        float* din;
+        hipMalloc(&din, 4096 * 4);
+        hipMemcpy(din, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+        for (int wpc = 1; wpc <= 2; ++wpc) {
+            float ms;
+            const int it = 2000;  // 64 MFMAs per iteration
+            hipLaunchKernelGGL(peak32_lds<false>, dim3(cus * wpc), dim3(256), 0, 0, out, din, 10);
+            hipEventRecord(e0);
+            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(peak32_lds<false>, dim3(cus * wpc), dim3(256), 0, 0, out, din, it);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            const double fl = 20.0 * 2.0 * 32 * 32 * 2 * 64.0 * it * 4.0 * cus * wpc;
+            printf(", \"mfma32x32x2_f32_tflops_lds_fed_wg%d\": %.1f", wpc, fl / ms * 1e-9);
+        }
+    }
+    // order check
+    const int steps = 16, trials = 200;
+    std::vector<float> A(steps * 64), B(steps * 64), C(256), D(256);
+    float *dA, *dB, *dC, *dD;
+    hipMalloc(&dA, A.size() * 4);
+    hipMalloc(&dB, B.size() * 4);
+    hipMalloc(&dC, 1024);
+    hipMalloc(&dD, 1024);
+    long bad_chain = 0, bad_pair = 0, total = 0;
+    srand(7);
+    for (int t = 0; t < trials; ++t) {
+        for (auto& v : A) v = rnd_wide();
+        for (auto& v : B) v = rnd_wide();
+        for (auto& v : C) v = (t & 1) ? 0.f : rnd_wide();
+        hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dC, C.data(), 1024, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(order16, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD, steps);
+        hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost);
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                float chain = C[i * 16 + j];
+                for (int s = 0; s < steps; ++s)
+                    for (int k = 0; k < 4; ++k) chain = fmaf(A[s * 64 + i * 4 + k], B[s * 64 + k * 16 + j], chain);
+                // alternative: pairwise (k0*k1 summed first) to show the check discriminates
+                float alt = C[i * 16 + j];
+                for (int s = 0; s < steps; ++s) {
+                    float p = 0.f;
+                    for (int k = 0; k < 4; ++k) p = fmaf(A[s * 64 + i * 4 + k], B[s * 64 + k * 16 + j], p);
+                    alt += p;
+                }
+                ++total;
+                if (memcmp(&chain, &D[i * 16 + j], 4)) ++bad_chain;
+                if (memcmp(&alt, &D[i * 16 + j], 4)) ++bad_pair;
+            }
+    }
+    printf(", \"order16x16x4\": {\"checked\": %ld, \"mismatch_vs_ordered_fmaf_chain\": %ld, \"mismatch_vs_blockwise_sum\": %ld}}\n",
+           total, bad_chain, bad_pair);
+    return 0;
+}
