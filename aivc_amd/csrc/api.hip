@@ -57,7 +57,7 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   if (rc != AIVC_OK) return rc;
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
   if (p->algo == AIVC_ALGO_DIRECT) return 0;
-  if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return 1;
+  if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin_variant(*p);
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
   return 0;
 }

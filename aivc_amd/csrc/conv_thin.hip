@@ -10,6 +10,8 @@
 //   - weights are wave-uniform: they arrive through the scalar cache as SGPR operands of v_fma_f32;
 //   - per output value the accumulation is the same (ky, kx) ascending / channel ascending fmaf chain
 //     as every other implementation (taps outside the image contribute fmaf(0, w, acc) = acc).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace aivc {
@@ -113,6 +115,203 @@ __global__ __launch_bounds__(TH * 16) void thin_tconv_kernel(aivc_conv_params p)
   }
 }
 
+// ---- matrix-core version -------------------------------------------------------------------------
+// The 4 parity classes x c_out outputs of one INPUT pixel form the N dimension of a small GEMM
+// (N = 12 or 24, padded to 16 / 32), K runs over the 3x3 input neighbourhood x c_in, and the class/tap
+// structure lives in the B operand: B[(dy, dx, ci)][class, o] = w[o][ky][kx][ci] with
+// ky = pyc + TPAD - 2 dy, kx = pxc + TPAD - 2 dx when that is a kernel tap of the class, else 0.
+// Walking the neighbourhood with dy, dx DESCENDING makes ky, kx ascend for every class at once, so each
+// output sees exactly the oracle's (ky, kx, ci)-ascending fmaf chain with exact no-ops (fmaf(x, 0, acc))
+// in between.  v_mfma_f32_16x16x4_f32 accumulates its 4 k-slots in order (tools/mfma_probe.hip checks it
+// against an fmaf chain), lane group g = lane / 16 supplies slot g, so inside every group of 16 channels
+// LDS position 4 g + e holds channel 4 e + g: one ds_read_b128 feeds 4 consecutive MFMA steps.
+// 52 % (c_out 3) / 39 % (c_out 6) of the MFMA work is useful, still 2-3x the VALU kernel above.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// Persistent workgroups (one per CU, 8 wavefronts): the B operand of a wavefront -- its 16 output columns
+// over all K = ND^2 * c_in -- is gathered from the weight tensor ONCE into registers (144 VGPRs at
+// c_in = 64), then the group walks over 4 x 32-pixel input tiles whose patches (tile + 1-pixel halo) are
+// double-buffered in LDS: the global loads of the next patch are in flight during the MFMAs of the
+// current one.  Wave roles: c_out 3 -> (row, half row), one 16-pixel group each; c_out 6 -> (row, N block),
+// two 16-pixel groups each.
+template <int KS, int CO, int G16>
+__global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int tiles_x, int tiles_y, int ntiles) {
+  constexpr int TH = 4, TW = 32, PW = TW + 2, PH = TH + 2;
+  constexpr int NB = (4 * CO + 15) / 16;
+  constexpr int NMG = NB;  // 16-pixel groups per wavefront
+  constexpr int TPAD = (KS + 1) / 2 - 1;
+  constexpr int LO = -((KS - 1 - TPAD) / 2), HI = (1 + TPAD) / 2;  // neighbourhood offsets carrying a tap
+  constexpr int ND = HI - LO + 1;
+  constexpr int NSTEP = ND * ND * G16;
+  constexpr int Cin = 16 * G16, SPX = Cin + 4, PATCH = PH * PW * SPX;
+  constexpr int UNITS = PH * PW * G16, UPT = (UNITS + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 patches [PH * PW][Cin + 4]
+  const int H = p.h_in, W = p.w_in;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int row = wave >> 1;
+  const int nb = NB == 2 ? (wave & 1) : 0, mg0 = NB == 2 ? 0 : (wave & 1);
+
+  // ---- this lane's output column and its B operand ------------------------------------------------
+  const int nc = nb * 16 + col;
+  const bool colok = nc < 4 * CO;
+  const int cls = colok ? nc / CO : 0, o = colok ? nc % CO : 0;
+  const int pyc = cls >> 1, pxc = cls & 1;
+  float breg[NSTEP][4];
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int t = step / G16, j16 = step % G16;
+    const int dy = HI - t / ND, dx = HI - t % ND;
+    const int ky = pyc + TPAD - 2 * dy, kx = pxc + TPAD - 2 * dx;
+    const bool ok = colok && ky >= 0 && ky < KS && kx >= 0 && kx < KS;
+    const float *src = p.w + (size_t)((o * KS + (ok ? ky : 0)) * KS + (ok ? kx : 0)) * Cin + j16 * 16 + g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = src[4 * e];
+      breg[step][e] = ok ? v : 0.0f;
+    }
+  }
+
+  // ---- patch staging: unit = 16 channels of one patch pixel ------------------------------------------
+  float4 sreg[UPT][4];
+  auto tile_origin = [&](int tile, int &n, int &ty0, int &tx0) {
+    const int per = tiles_x * tiles_y;
+    n = tile / per;
+    const int r = tile - n * per;
+    ty0 = (r / tiles_x) * TH;
+    tx0 = (r % tiles_x) * TW;
+  };
+  auto stage_load = [&](int tile) {
+    int n, ty0, tx0;
+    tile_origin(tile, n, ty0, tx0);
+    const float *xn = p.x + (size_t)n * H * W * Cin;
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int i = tid + 512 * u;
+      const int j16 = i % G16, pp = i / G16;
+      const int iy = ty0 - 1 + pp / PW, ix = tx0 - 1 + pp % PW;
+      const bool ok = i < UNITS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float *src = xn + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * Cin + j16 * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * e);
+        sreg[u][e] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto stage_store = [&](float *buf) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int i = tid + 512 * u;
+      if (i < UNITS) {
+        float *dst = buf + (i / G16) * SPX + (i % G16) * 16;  // position 4 g + e <- channel 4 e + g
+        *reinterpret_cast<float4 *>(dst) = make_float4(sreg[u][0].x, sreg[u][1].x, sreg[u][2].x, sreg[u][3].x);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(sreg[u][0].y, sreg[u][1].y, sreg[u][2].y, sreg[u][3].y);
+        *reinterpret_cast<float4 *>(dst + 8) = make_float4(sreg[u][0].z, sreg[u][1].z, sreg[u][2].z, sreg[u][3].z);
+        *reinterpret_cast<float4 *>(dst + 12) = make_float4(sreg[u][0].w, sreg[u][1].w, sreg[u][2].w, sreg[u][3].w);
+      }
+    }
+  };
+
+  const bool has_bias = p.bias != nullptr;
+  const float bias_o = (has_bias && colok) ? p.bias[o] : 0.0f;
+  const int act1 = p.act1, act2 = p.act2;
+  // A fragments: corner (LO, LO) of the neighbourhood of this lane's pixel; steps add constant offsets
+  const int a_off = ((row + 1 + LO) * PW + 1 + LO + mg0 * 16 + col) * SPX + 4 * g;
+
+  int tile = blockIdx.x, cur = 0;
+  if (tile < ntiles) {
+    stage_load(tile);
+    stage_store(smem);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stage_load(next);
+    const float *ap = smem + cur * PATCH + a_off;
+    floatx4 acc[NMG];
+#pragma unroll
+    for (int mg = 0; mg < NMG; ++mg) acc[mg] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int t = step / G16, j16 = step % G16;
+      const int dy = HI - t / ND, dx = HI - t % ND;
+      float4 af[NMG];
+#pragma unroll
+      for (int mg = 0; mg < NMG; ++mg)
+        af[mg] = *reinterpret_cast<const float4 *>(ap + ((dy - LO) * PW + (dx - LO) + mg * 16) * SPX + j16 * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mg = 0; mg < NMG; ++mg) {
+          const float av = e == 0 ? af[mg].x : (e == 1 ? af[mg].y : (e == 2 ? af[mg].z : af[mg].w));
+          acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[step][e], acc[mg], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: lane (col, g) holds rows 4 g + r of its 16-pixel groups ---------------------------
+    {
+      int n, ty0, tx0;
+      tile_origin(tile, n, ty0, tx0);
+      const int qy = ty0 + row;
+      if (colok && qy < H) {
+#pragma unroll
+        for (int mg = 0; mg < NMG; ++mg)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qx = tx0 + (mg0 + mg) * 16 + 4 * g + r;
+            if (qx < W) {
+              const size_t off = (((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc)) * CO + o;
+              float v = acc[mg][r];
+              if (has_bias) v = v + bias_o;
+              v = v > 0.0f ? v : (act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v));
+              if (p.mul) v = p.mul[off] * v;
+              if (p.res) v = v + p.res[off];
+              v = v > 0.0f ? v : (act2 == AIVC_ACT_LEAKY ? v * 0.01f : (act2 == AIVC_ACT_RELU ? 0.0f : v));
+              p.y[off] = v;
+            }
+          }
+      }
+    }
+    if (next < ntiles) stage_store(smem + (cur ^ 1) * PATCH);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+static bool thin_mfma_ok(const aivc_conv_params &p) {
+  if (p.c_in != 16 && p.c_in != 32 && p.c_in != 64) return false;  // instantiated widths (B operand in registers)
+  return p.act1 != AIVC_ACT_SIGMOID && p.act2 != AIVC_ACT_SIGMOID;
+}
+
+template <int KS, int CO, int G16>
+static int launch_thin_mfma_g(const aivc_conv_params &p, hipStream_t s) {
+  const size_t lds = (size_t)2 * 6 * 34 * (16 * G16 + 4) * sizeof(float);
+  const int tiles_x = (p.w_in + 31) / 32, tiles_y = (p.h_in + 3) / 4;
+  const int ntiles = tiles_x * tiles_y * p.n;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(thin_mfma_kernel<KS, CO, G16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  hipLaunchKernelGGL((thin_mfma_kernel<KS, CO, G16>), dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y, ntiles);
+  return check_launch("thin_mfma");
+}
+
+template <int KS, int CO>
+static int launch_thin_mfma(const aivc_conv_params &p, hipStream_t s) {
+  switch (p.c_in) {
+    case 16: return launch_thin_mfma_g<KS, CO, 1>(p, s);
+    case 32: return launch_thin_mfma_g<KS, CO, 2>(p, s);
+    default: return launch_thin_mfma_g<KS, CO, 4>(p, s);
+  }
+}
+
 bool conv2d_thin_supported(const aivc_conv_params &p) {
   if (p.mode != AIVC_MODE_TCONV || p.gdn) return false;
   if (p.c_out != 3 && p.c_out != 6) return false;
@@ -135,8 +334,14 @@ static int launch_thin(const aivc_conv_params &p, hipStream_t s) {
   return check_launch("thin_tconv");
 }
 
+int conv2d_thin_variant(const aivc_conv_params &p) { return thin_mfma_ok(p) && !getenv("AIVC_THIN_VALU") ? 2 : 1; }
+
 int conv2d_thin(const aivc_conv_params &p, hipStream_t s) {
   if (!conv2d_thin_supported(p)) return AIVC_ERR_UNSUPPORTED;
+  if (thin_mfma_ok(p) && !getenv("AIVC_THIN_VALU")) {
+    if (p.ksize == 5) return p.c_out == 3 ? launch_thin_mfma<5, 3>(p, s) : launch_thin_mfma<5, 6>(p, s);
+    return p.c_out == 3 ? launch_thin_mfma<3, 3>(p, s) : launch_thin_mfma<3, 6>(p, s);
+  }
   if (p.ksize == 5) return p.c_out == 3 ? launch_thin<5, 3>(p, s) : launch_thin<5, 6>(p, s);
   return p.c_out == 3 ? launch_thin<3, 3>(p, s) : launch_thin<3, 6>(p, s);
 }

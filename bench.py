@@ -35,6 +35,8 @@ def variant_name(v):
         return 'conv_direct_kernel'
     if v == 1:
         return 'thin_tconv_kernel'
+    if v == 2:
+        return 'thin_mfma_kernel'
     c = v - 100
     fused = c >= 50
     c -= 50 if fused else 0

@@ -54,6 +54,12 @@ CONV_CASES = [
     (abi.MODE_TCONV, 3, 2, 0, 64, 3, 17, 33, abi.ACT_LEAKY, 0, False, True),
     (abi.MODE_TCONV, 5, 2, 0, 128, 3, 9, 19, 0, 0, False, False),
     (abi.MODE_TCONV, 5, 2, 0, 16, 6, 16, 16, 0, abi.ACT_RELU, False, True),
+    # thin outputs on the 16x16x4 MFMA kernel: partial tiles in x and y, several tiles, gate + residual
+    (abi.MODE_TCONV, 5, 2, 0, 64, 3, 19, 70, abi.ACT_LEAKY, 0, True, False),
+    (abi.MODE_TCONV, 3, 2, 0, 32, 6, 9, 40, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 48, 6, 8, 33, 0, abi.ACT_LEAKY, True, True),
+    (abi.MODE_TCONV, 3, 2, 0, 96, 3, 1, 1, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 64, 6, 6, 10, abi.ACT_SIGMOID, 0, False, False),  # falls back to the VALU kernel
 ]
 
 

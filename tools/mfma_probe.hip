@@ -52,16 +52,18 @@ __global__ __launch_bounds__(256) void peak32_rand(float* out, const float* in, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-// The conv kernel's inner loop in isolation: operands come from LDS with the same row stride / fragment
-// addressing (ds_read_b128 per 4 MFMA steps), 2x2 accumulator blocks per wave, no barriers, no global loads.
+// The conv kernel's K loop rebuilt feature by feature (FEAT bits): operands always come from LDS with the
+// kernel's row stride / fragment addressing (ds_read_b128 per 4 MFMA steps, 2x2 accumulator blocks per wave);
+//   1 = the two barriers per K-tile, 2 = the 8 ds_write_b128 of the staged tile, 4 = the 8 global_load_dwordx4
+// of the next tile (128-byte rows out of a large buffer), 8 = the even/odd K permutation (v_mov) before the writes.
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <bool PIPE>
-__global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in, int iters) {
+template <int FEAT>
+__global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in, int iters, const float* big, unsigned big_mask) {
     constexpr int STRIDE = 36;
     __shared__ __attribute__((aligned(16))) float smem[256 * STRIDE];
     for (int i = threadIdx.x; i < 256 * STRIDE; i += 256) smem[i] = in[i & 4095];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const float* a_frag = smem + (wm * 64 + (lane & 31)) * STRIDE + (lane >> 5) * 4;
     const float* b_frag = smem + 128 * STRIDE + (wn * 64 + (lane & 31)) * STRIDE + (lane >> 5) * 4;
@@ -69,7 +71,49 @@ __global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f4 st[4][2];
+    for (int u = 0; u < 4; ++u)
+        for (int q = 0; q < 2; ++q) st[u][q] = *reinterpret_cast<const f4*>(in + ((tid * 8 + u * 64 + q * 4) & 4095));
     for (int it = 0; it < iters; ++it) {
+        if (FEAT & 1) __syncthreads();
+        if (FEAT & 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float* dst = smem + ((tid + 256 * u) >> 2) * STRIDE + ((tid + 256 * u) & 3) * 8;
+                if (FEAT & 8) {
+                    f4 lo = {st[u][0][0], st[u][0][2], st[u][1][0], st[u][1][2]};
+                    f4 hi = {st[u][0][1], st[u][0][3], st[u][1][1], st[u][1][3]};
+                    *reinterpret_cast<f4*>(dst) = lo;
+                    *reinterpret_cast<f4*>(dst + 4) = hi;
+                } else {
+                    *reinterpret_cast<f4*>(dst) = st[u][0];
+                    *reinterpret_cast<f4*>(dst + 4) = st[u][1];
+                }
+            }
+        }
+        if (FEAT & 1) __syncthreads();
+        if (FEAT & 4) {
+            // the access pattern of a 3x3 conv over 128 channels at 135x240: per K-tile, 128 pixel rows x 128 B
+            // (4 lanes share a 128-B line), 4 K-tiles per tap walk through one 512-B pixel record, taps re-touch
+            // neighbouring pixels; weights: 128 rows of 1152 floats, L2 resident
+            const int kt = it % 36, tap = kt >> 2, chunk = kt & 3;
+            const unsigned npix = 8u * 135u * 240u;
+            const unsigned tile = (blockIdx.x + (unsigned)(it / 36) * gridDim.x) % (npix / 128u);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int pix = (int)(tile * 128u) + (tid >> 2) + 64 * u + (tap / 3 - 1) * 240 + (tap % 3 - 1);
+                pix = pix < 0 ? 0 : (pix >= (int)npix ? (int)npix - 1 : pix);
+                const float* src = big + (size_t)pix * 128 + chunk * 32 + (tid & 3) * 8;
+                st[u][0] = *reinterpret_cast<const f4*>(src);
+                st[u][1] = *reinterpret_cast<const f4*>(src + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float* src = big + (size_t)npix * 128 + (size_t)((tid >> 2) + 64 * u) * 1152 + kt * 32 + (tid & 3) * 8;
+                st[2 + u][0] = *reinterpret_cast<const f4*>(src);
+                st[2 + u][1] = *reinterpret_cast<const f4*>(src + 4);
+            }
+        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             f4 af[2], bf[2];
@@ -85,14 +129,27 @@ __global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (PIPE) __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
     }
     float s = 0.f;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    for (int u = 0; u < 4; ++u) s += st[u][0][0] + st[u][1][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int FEAT>
+static double run_lds(float* out, const float* din, const float* big, unsigned mask, int cus, hipEvent_t e0, hipEvent_t e1) {
+    float ms;
+    const int it = 36 * 56, wpc = 2;
+    hipLaunchKernelGGL(peak32_lds<FEAT>, dim3(cus * wpc), dim3(256), 0, 0, out, din, 10, big, mask);
+    hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(peak32_lds<FEAT>, dim3(cus * wpc), dim3(256), 0, 0, out, din, it, big, mask);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    return 10.0 * 2.0 * 32 * 32 * 2 * 64.0 * it * 4.0 * cus * wpc / ms * 1e-9;
 }
 
 template <int K>
@@ -198,18 +255,18 @@ int main() {
         float* din;
         hipMalloc(&din, 4096 * 4);
         hipMemcpy(din, h.data(), 4096 * 4, hipMemcpyHostToDevice);
-        for (int wpc = 1; wpc <= 2; ++wpc) {
-            float ms;
-            const int it = 2000;  // 64 MFMAs per iteration
-            hipLaunchKernelGGL(peak32_lds<false>, dim3(cus * wpc), dim3(256), 0, 0, out, din, 10);
-            hipEventRecord(e0);
-            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(peak32_lds<false>, dim3(cus * wpc), dim3(256), 0, 0, out, din, it);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            hipEventElapsedTime(&ms, e0, e1);
-            const double fl = 20.0 * 2.0 * 32 * 32 * 2 * 64.0 * it * 4.0 * cus * wpc;
-            printf(", \"mfma32x32x2_f32_tflops_lds_fed_wg%d\": %.1f", wpc, fl / ms * 1e-9);
-        }
+        float* big;
+        const unsigned big_elems = 1u << 26;  // 256 MB
+        hipMalloc(&big, (size_t)big_elems * 4);
+        hipMemset(big, 0, (size_t)big_elems * 4);
+        const unsigned mask = (big_elems - 1) & ~31u;
+        printf(", \"lds_fed_loop_tflops\": {\"mfma_only\": %.1f", run_lds<0>(out, din, big, mask, cus, e0, e1));
+        printf(", \"+barriers\": %.1f", run_lds<1>(out, din, big, mask, cus, e0, e1));
+        printf(", \"+barriers+ds_write\": %.1f", run_lds<3>(out, din, big, mask, cus, e0, e1));
+        printf(", \"+barriers+ds_write+perm\": %.1f", run_lds<11>(out, din, big, mask, cus, e0, e1));
+        printf(", \"+global_loads\": %.1f", run_lds<4>(out, din, big, mask, cus, e0, e1));
+        printf(", \"+barriers+ds_write+global_loads\": %.1f", run_lds<7>(out, din, big, mask, cus, e0, e1));
+        printf(", \"all\": %.1f}", run_lds<15>(out, din, big, mask, cus, e0, e1));
     }
     // order check
     const int steps = 16, trials = 200;
