@@ -5,6 +5,7 @@ reference spreads over FullNet.GOP_forward (missing from the snapshot), Decoder.
 device->host CDF copies.  Frames are dicts {'y','u','v'} of uint8 CUDA planes [1,h,w] (8-bit
 references are exact: the reference casts every reconstruction to 8-bit levels, decode.py:575).
 """
+import contextlib
 import math
 
 import torch
@@ -13,7 +14,7 @@ from . import ops
 from .func_util.GOP_structure import FRAME_B, FRAME_I, FRAME_P, coding_levels, generate_gop_struct
 from .real_life import cat_binary_files as container
 from .real_life import header as hdr
-from .real_life.bitstream import finalize_frames, launch_finalize, split_sections
+from .real_life.bitstream import finalize_frames, launch_finalize, prepare_finalize, split_sections
 
 
 def frame_index(name):
@@ -32,9 +33,11 @@ class FrameCodec:
     """max_batch bounds how many frames of one dependency level are pushed through the transforms
     together (activations of a 1080p frame at 1/2 resolution are 133 MB per 64-channel tensor)."""
 
-    def __init__(self, full_net, max_batch=8, entropy_chunk=64):
+    def __init__(self, full_net, max_batch=8, entropy_chunk=64, entropy_streams=4, entropy_lookahead=2):
         self.net = full_net
         self.entropy_chunk = entropy_chunk
+        self.entropy_streams = max(2, entropy_streams)  # decoder: concurrent range-coder chains
+        self.entropy_lookahead = max(1, entropy_lookahead)  # ... issued this many dependency levels ahead
         self.mof = full_net.mode_net.mode_net
         self.cod = full_net.codec_net.codec_net
         self.max_batch = max_batch
@@ -106,24 +109,33 @@ class FrameCodec:
             res['aux'] = out['aux']
         return res
 
-    def entropy_decode(self, frames_bytes, frame_type, data_dim, idx_rate=0., device=None):
+    def entropy_decode(self, frames_bytes, frame_type, data_dim, idx_rate=0., device=None, streams=None):
         """Entropy stage of the decoder for n frames of one type: z streams -> h_s -> (mu, sigma) ->
         y streams -> y_hat.  It depends on the bitstream only (never on reconstructed frames), so the
         caller may run it for every frame of a video up front, all streams concurrently.
-        -> {'mof': y_hat [n,h_y,w_y,C] or None, 'cod': y_hat}"""
+        -> {'mof': y_hat [n,h_y,w_y,C] or None, 'cod': y_hat}
+        streams: optional list of HIP streams; the two networks' chains (z streams -> h_s -> y streams) are
+        independent and go to streams[0] / streams[1]; then -> (dict, [event per chain])."""
         device = device or torch.device('cuda')
         secs = [split_sections(b) for b in frames_bytes]
         h_y, w_y = data_dim['y']
         h_z, w_z = data_dim['z']
         out = {'mof': None}
-        for name, net, iz, iy in (('mof', self.mof, 0, 1), ('cod', self.cod, 2, 3)):
+        events = []
+        for k, (name, net, iz, iy) in enumerate((('mof', self.mof, 0, 1), ('cod', self.cod, 2, 3))):
             if name == 'mof' and frame_type == FRAME_I:
                 continue
-            q_z = net.ac.decode_z([s[iz] for s in secs], h_z, w_z, net.nb_ft_z, device)
-            pay_y = [s[iy] for s in secs]
-            out[name] = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(pay_y, sigma), frame_type,
-                                                 (h_y, w_y), idx_rate)
-        return out
+            ctx = torch.cuda.stream(streams[k % len(streams)]) if streams else contextlib.nullcontext()
+            with ctx:
+                q_z = net.ac.decode_z([s[iz] for s in secs], h_z, w_z, net.nb_ft_z, device)
+                pay_y = [s[iy] for s in secs]
+                out[name] = net.latents_from_symbols(q_z, lambda sigma: net.ac.decode_y(pay_y, sigma), frame_type,
+                                                     (h_y, w_y), idx_rate)
+                if streams:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    events.append(ev)
+        return (out, events) if streams else out
 
     def synthesise_batch(self, y_hats, prev, nxt, frame_type, data_dim):
         """Reconstruction stage (mirror of Decoder.decode, src/real_life/decode.py:455-580) for n frames
@@ -158,9 +170,16 @@ class FrameCodec:
     # entropy streams are coded concurrently.  Frames are stored in display order in the container,
     # so this yields the same bytes as the reference's depth-first order.
     def _side_stream(self):
-        if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(priority=-1)  # entropy coder: few waves, latency critical
-        return self._side
+        return self._side_streams(1)[0]
+
+    def _side_streams(self, k):
+        """k high-priority streams for the entropy coder (few waves each, latency critical)"""
+        pool = getattr(self, '_sides', None)
+        if pool is None:
+            pool = self._sides = []
+        while len(pool) < k:
+            pool.append(torch.cuda.Stream(priority=-1))
+        return pool[:k]
 
     def _chunks(self, gop, level, unit_ids):
         """(frame type, [(unit, frame name), ...]) batches of at most max_batch same-type frames of one
@@ -180,6 +199,7 @@ class FrameCodec:
         data_dim = None
         side = self._side_stream()
         jobs = []
+        waiting = None  # (items, sections, flags on their way to the host) of the previous level
         for level in coding_levels(gop):
             pending = []
             for ftype, chunk in self._chunks(gop, level, range(len(units))):
@@ -190,10 +210,17 @@ class FrameCodec:
                 for (u, f), r in zip(chunk, out['rec']):
                     rec[u][f] = r
                 pending.append((chunk, out['sections']))
-            # entropy-code the whole level on the side stream (one sync for the map flags, one batched
-            # launch); the next level's transforms run meanwhile on the main stream
+            # entropy coding runs on the side stream one level behind the transforms: the flags of THIS level
+            # start their trip to the host now, the host picks them up (and launches the range coder) only
+            # after the next level's transforms are queued, so the main stream never drains on that wait
             all_secs = [s for _, secs in pending for s in secs]
-            jobs.append(([it for chunk, _ in pending for it in chunk], launch_finalize(all_secs, side)))
+            items = [it for chunk, _ in pending for it in chunk]
+            prep = prepare_finalize(all_secs)
+            if waiting is not None:
+                jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2])))
+            waiting = (items, all_secs, prep)
+        if waiting is not None:
+            jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2])))
         for items, job in jobs:
             for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b
@@ -217,35 +244,38 @@ class FrameCodec:
             # entropy stage on the (high priority) side stream, one dependency level ahead of the
             # synthesis stage on the main stream; the host alternates between the two so that both
             # queues stay fed
-            main, side = torch.cuda.current_stream(), self._side_stream()
-            side.wait_stream(main)
+            main, sides = torch.cuda.current_stream(), self._side_streams(self.entropy_streams)
+            for sd in sides:
+                sd.wait_stream(main)
             levels = coding_levels(gop)
             lat, ready = {}, {}
+            rr = [0]
 
             def issue_entropy(level):
                 for ftype in sorted({gop[f]['type'] for f in level}):
                     items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
                     for s0 in range(0, len(items), self.entropy_chunk):
                         chunk = items[s0:s0 + self.entropy_chunk]
-                        with torch.cuda.stream(side):
-                            yh = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype,
-                                                     data_dim, idx_rate, device)
-                            ev = torch.cuda.Event()
-                            ev.record(side)
+                        pair = [sides[(rr[0] + k) % len(sides)] for k in range(2)]
+                        rr[0] += 2
+                        yh, evs = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype,
+                                                      data_dim, idx_rate, device, streams=pair)
                         for v in yh.values():
                             if v is not None:
                                 v.record_stream(main)
                         for j, it in enumerate(chunk):
                             lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
-                            ready[it] = ev
+                            ready[it] = evs
 
             rec = {i: {} for i in members}
-            issue_entropy(levels[0])
+            ahead = self.entropy_lookahead
+            for li in range(min(ahead, len(levels))):
+                issue_entropy(levels[li])
             for li, level in enumerate(levels):
-                if li + 1 < len(levels):
-                    issue_entropy(levels[li + 1])
+                if li + ahead < len(levels):
+                    issue_entropy(levels[li + ahead])
                 for ftype, chunk in self._chunks(gop, level, members):
-                    for ev in {id(ready[it]): ready[it] for it in chunk}.values():
+                    for ev in {id(e): e for it in chunk for e in ready[it]}.values():
                         main.wait_event(ev)
                     yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
                           for k in ('mof', 'cod')}

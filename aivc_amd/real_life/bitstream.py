@@ -109,20 +109,51 @@ class EntropyJob:
         return frames
 
 
-def launch_finalize(frames_sections, side_stream=None):
-    """frames_sections: list (one entry per frame) of 4-lists of PendingSection / None.
-    One host sync for all non-zero-map flags (C bytes per latent), then the CDF-bound kernels and ONE
-    batched range-encode launch per 64 streams (a wavefront per stream, all concurrent) and an async
-    D2H -- on `side_stream` when given, so the transforms of the next frames overlap with it."""
+class PreparedFlags:
+    """Non-zero-map flags of a set of frames on their way to the host (async D2H + event on the stream that
+    produced the latents)."""
+
+    def __init__(self, lap, flags_h, event):
+        self.lap, self.flags_h, self.event = lap, flags_h, event
+
+
+def prepare_finalize(frames_sections):
+    """Phase 1 of launch_finalize, no host sync: queue the D2H copy of the non-zero-map flags behind the
+    kernels that produced the latents and record an event.  A caller that has more GPU work to issue (the
+    next dependency level) does that between prepare_finalize and launch_finalize, so the host wait of
+    phase 2 overlaps with it instead of draining the main stream."""
     lap = [(fi, si, s) for fi, secs in enumerate(frames_sections) for si, s in enumerate(secs)
            if s is not None and s.mode == 'laplace']
-    flags_h = torch.stack([s.flags for _, _, s in lap]).cpu().numpy() if lap else None  # the one sync
+    flags_h = None
+    if lap:
+        flags_d = torch.stack([s.flags for _, _, s in lap])
+        flags_h = _pinned(flags_d.numel(), torch.uint8)
+        flags_h.copy_(flags_d.reshape(-1), non_blocking=True)
+        flags_h = (flags_h, tuple(flags_d.shape), flags_d)
+    event = torch.cuda.Event()
+    event.record()
+    return PreparedFlags(lap, flags_h, event)
+
+
+def launch_finalize(frames_sections, side_stream=None, prepared=None):
+    """frames_sections: list (one entry per frame) of 4-lists of PendingSection / None.
+    One host wait for all non-zero-map flags (C bytes per latent), then the CDF-bound kernels and ONE
+    batched range-encode launch per 64 streams (a wavefront per stream, all concurrent) and an async
+    D2H -- on `side_stream` when given, so the transforms of the next frames overlap with it."""
+    if prepared is None:
+        prepared = prepare_finalize(frames_sections)
+    lap = prepared.lap
+    prepared.event.synchronize()  # the one host wait
+    flags_h = None
+    if lap:
+        buf, shape, _ = prepared.flags_h
+        flags_h = buf.numpy().reshape(shape).copy()
+        _unpin(buf)
     present = [[s is not None for s in secs] for secs in frames_sections]
     heads = [[b''] * 4 for _ in frames_sections]
-    main = torch.cuda.current_stream()
     ctx = torch.cuda.stream(side_stream) if side_stream is not None else None
     if ctx is not None:
-        side_stream.wait_stream(main)
+        side_stream.wait_event(prepared.event)  # the latents of THESE frames, not whatever was issued since
         ctx.__enter__()
     try:
         jobs, bounds = [], []
