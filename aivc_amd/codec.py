@@ -197,7 +197,8 @@ class FrameCodec:
         rec = [dict() for _ in units]
         fbytes = [dict() for _ in units]
         data_dim = None
-        side = self._side_stream()
+        sides = self._side_streams(self.entropy_streams)
+        side, forks = sides[0], sides[1:]
         jobs = []
         waiting = None  # (items, sections, flags on their way to the host) of the previous level
         for level in coding_levels(gop):
@@ -217,10 +218,10 @@ class FrameCodec:
             items = [it for chunk, _ in pending for it in chunk]
             prep = prepare_finalize(all_secs)
             if waiting is not None:
-                jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2])))
+                jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2], fork_streams=forks)))
             waiting = (items, all_secs, prep)
         if waiting is not None:
-            jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2])))
+            jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2], fork_streams=forks)))
         for items, job in jobs:
             for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b

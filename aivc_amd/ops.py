@@ -358,10 +358,12 @@ def _pinned_release(view):
     _STAGING.append((ev, base))
 
 
-def range_encode(bounds_list):
+def range_encode(bounds_list, streams=None):
     """bounds_list: int32 CUDA tensors, one independent stream each (any number; launched 64 at a
     time, one wavefront per stream).  Returns (out uint8 tensor, lens int32 tensor [n], [(offset,
-    capacity)]) -- all on device, no sync."""
+    capacity)]) -- all on device, no sync.
+    streams: optional HIP streams; the launches (a kernel lasts as long as its longest stream) then
+    run concurrently on them, forked from / joined back into the current stream with events."""
     n = len(bounds_list)
     dev = bounds_list[0].device
     allb = bounds_list[0] if n == 1 else torch.cat(bounds_list)
@@ -374,7 +376,16 @@ def range_encode(bounds_list):
         out_off += cap
     out = torch.empty(out_off, dtype=torch.uint8, device=dev)
     lens = torch.empty(n, dtype=torch.int32, device=dev)
-    for start in range(0, n, abi.RC_MAX_STREAMS):
+    fork = streams is not None and len(streams) > 0 and n > abi.RC_MAX_STREAMS
+    cur, ev0 = None, None
+    if fork:
+        cur = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(cur)
+        for t in (allb, out, lens):
+            for st in streams:
+                t.record_stream(st)
+    for gi, start in enumerate(range(0, n, abi.RC_MAX_STREAMS)):
         batch = abi.RcBatch()
         cnt = 0
         for i in range(start, min(n, start + abi.RC_MAX_STREAMS)):
@@ -382,7 +393,15 @@ def range_encode(bounds_list):
             s_.in_off, s_.out_off, s_.n_sym, s_.out_cap = in_offs[i], out_offs[i][0], bounds_list[i].numel(), out_offs[i][1]
             cnt += 1
         batch.n_streams = cnt
-        call('aivc_range_encode', _p(allb), C.byref(batch), _p(out), lens.data_ptr() + 4 * start, _stream())
+        if fork:
+            st = streams[gi % len(streams)]
+            st.wait_event(ev0)
+            call('aivc_range_encode', _p(allb), C.byref(batch), _p(out), lens.data_ptr() + 4 * start, st.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            cur.wait_event(ev)
+        else:
+            call('aivc_range_encode', _p(allb), C.byref(batch), _p(out), lens.data_ptr() + 4 * start, _stream())
     return out, lens, out_offs
 
 

@@ -135,11 +135,12 @@ def prepare_finalize(frames_sections):
     return PreparedFlags(lap, flags_h, event)
 
 
-def launch_finalize(frames_sections, side_stream=None, prepared=None):
+def launch_finalize(frames_sections, side_stream=None, prepared=None, fork_streams=None):
     """frames_sections: list (one entry per frame) of 4-lists of PendingSection / None.
     One host wait for all non-zero-map flags (C bytes per latent), then the CDF-bound kernels and ONE
     batched range-encode launch per 64 streams (a wavefront per stream, all concurrent) and an async
-    D2H -- on `side_stream` when given, so the transforms of the next frames overlap with it."""
+    D2H -- on `side_stream` when given, so the transforms of the next frames overlap with it; with
+    `fork_streams` the 64-stream launches of a big set run side by side instead of back to back."""
     if prepared is None:
         prepared = prepare_finalize(frames_sections)
     lap = prepared.lap
@@ -171,7 +172,7 @@ def launch_finalize(frames_sections, side_stream=None, prepared=None):
         out_h = lens_h = offs = event = None
         keep = [frames_sections, bounds]
         if jobs:
-            out, lens, offs = ops.range_encode(bounds)
+            out, lens, offs = ops.range_encode(bounds, streams=fork_streams)
             out_h = _pinned(out.numel(), torch.uint8)
             lens_h = _pinned(lens.numel(), torch.int32)
             out_h.copy_(out, non_blocking=True)
