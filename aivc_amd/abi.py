@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 AIVC_OK = 0
 ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
@@ -65,6 +65,9 @@ _P = C.POINTER
 
 # name -> argtypes (without the trailing stream argument, which every entry takes)
 PROTOTYPES = {
+    'aivc_ssim_means': [_f, _f, _i32, _i32, _i32, _f, _i32, C.c_double, C.c_double, _f, _f],
+    'aivc_pool2x2': [_f, _i32, _i32, _i32, _i32, _f],
+    'aivc_sq_err': [_f, _f, _sz, _f, _f],
     'aivc_conv2d': [_P(ConvParams)],
     'aivc_gdn_reparam': [_f, _f, _i32, _fl, _fl, _fl, _f, _f],
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
@@ -104,6 +107,10 @@ def declare(lib, suffix=''):
         var.argtypes = [_P(ConvParams)]
         var.restype = C.c_int
         fns['aivc_conv2d_variant'] = var
+    mws = getattr(lib, 'aivc_metrics_workspace' + suffix)
+    mws.argtypes = [_i32, _i32, _i32]
+    mws.restype = C.c_size_t
+    fns['aivc_metrics_workspace'] = mws
     ver = getattr(lib, 'aivc_abi_version' + suffix)
     ver.argtypes = []
     ver.restype = C.c_int

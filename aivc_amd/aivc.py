@@ -1,15 +1,13 @@
 #!/usr/bin/env python3
-"""aivc.py CLI (flags of src/aivc.py:16-76): encode, decode, report size + PSNR -- in one process
+"""aivc.py CLI (flags of src/aivc.py:16-76): encode, decode, evaluate (PSNR, MS-SSIM, size) -- in one process
 (the reference forks three python processes and goes through PNG triplets)."""
 import argparse
 import os
 import sys
 
-import numpy as np
-
 from aivc_amd import decode as dec_cli
 from aivc_amd import encode as enc_cli
-from aivc_amd.real_life.encode import parse_yuv_name
+from aivc_amd import evaluate as eval_cli
 
 
 def gop_name(cfg, gop_size, intra_period):
@@ -51,14 +49,8 @@ def main(argv=None):
     print('Starting decoding'.center(120))
     dec_cli.main(['-i', a.bitstream_out, '-o', a.o] + common)
     print(('*' * 80).center(120))
-    w, h = parse_yuv_name(a.i)
-    fsz = h * w + 2 * ((h + 1) // 2) * ((w + 1) // 2)
-    raw = np.fromfile(a.i, np.uint8, offset=a.start_frame * fsz)
-    dec = np.fromfile(a.o if a.o.endswith('.yuv') else a.o + '.yuv', np.uint8)
-    raw = raw[:dec.size].astype(np.float64)
-    mse = float(np.mean((raw - dec) ** 2))
-    print('PSNR    [dB]: %.5f' % (10 * np.log10(255.0 ** 2 / max(mse, 1e-12))))
-    print('Size [bytes]: %d' % os.path.getsize(a.bitstream_out))
+    print('Starting evaluation'.center(120))
+    eval_cli.main(['--raw', a.i, '--compressed', a.o, '--bitstream', a.bitstream_out, '--start_frame', str(a.start_frame)])
 
 
 if __name__ == '__main__':

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import abi
-from ._lib import AivcNativeError, call
+from ._lib import AivcNativeError, call, load
 
 FRAME_I, FRAME_P, FRAME_B = abi.FRAME_I, abi.FRAME_P, abi.FRAME_B
 
@@ -449,3 +449,40 @@ def scatter_symbols(sym, npix, c, maps):
     q = torch.empty((npix, c), dtype=torch.int16, device=dev)
     call('aivc_scatter_symbols', _p(sym), npix, c, C.byref(ml), _p(q), _stream())
     return q
+
+
+# ---- quality metrics (fp64 planes [n, h, w]) ------------------------------------------------------
+def _metrics_ws(n, h, w, dev):
+    nbytes = load()['aivc_metrics_workspace'](int(n), int(h), int(w))
+    return torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+
+
+def ssim_means(a, b, win, c1, c2):
+    """a, b: float64 CUDA planes [n,h,w]; win: 1-D normalised window (host sequence, len <= 11).
+    -> float64 CUDA tensor [n, 2]: (mean SSIM, mean contrast-structure) of one scale."""
+    a, b = _dev(a, torch.float64, 'a'), _dev(b, torch.float64, 'b')
+    n, h, w = a.shape
+    wn = np.ascontiguousarray(np.asarray(win, np.float64))
+    out = torch.empty((n, 2), dtype=torch.float64, device=a.device)
+    ws = _metrics_ws(n, h, w, a.device)
+    call('aivc_ssim_means', _p(a), _p(b), n, h, w, wn.ctypes.data, len(wn), float(c1), float(c2), _p(ws), _p(out), _stream())
+    return out
+
+
+def pool2x2(x, edge):
+    """float64 planes [n,h,w] -> [n, ceil(h/2), ceil(w/2)] 2x2 means; edge 0: mirror past the end without
+    repeating the border (torch ReflectionPad2d), 1: repeat it (scipy 'reflect')."""
+    x = _dev(x, torch.float64, 'x')
+    n, h, w = x.shape
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2), dtype=torch.float64, device=x.device)
+    call('aivc_pool2x2', _p(x), n, h, w, int(edge), _p(out), _stream())
+    return out
+
+
+def sq_err(a, b):
+    """-> float64 CUDA tensor [1]: sum of squared differences of two float64 tensors of equal size"""
+    a, b = _dev(a, torch.float64, 'a'), _dev(b, torch.float64, 'b')
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    ws = _metrics_ws(1, 16, 16, a.device)
+    call('aivc_sq_err', _p(a), _p(b), a.numel(), _p(ws), _p(out), _stream())
+    return out

@@ -53,7 +53,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 2 */
+int aivc_abi_version(void); /* currently 3 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -283,6 +283,24 @@ int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_
  * all other channels 0.  (src/real_life/bitstream.py:458-466) */
 int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c, const aivc_map_list *maps,
                          int16_t *q, aivc_stream_t stream);
+
+/* ---- quality metrics, fp64 planes [n][h][w] on the device -------------------------
+ * Scratch for the three calls below, in bytes (for the largest plane they will see). */
+size_t aivc_metrics_workspace(int32_t n, int32_t h, int32_t w);
+/* One MS-SSIM scale: out[i][0] = mean SSIM map, out[i][1] = mean contrast-structure (v1/v2) of plane i, with a
+ * ws x ws "valid" window win (x) win (HOST pointer, ws <= 11, normalised 1-D Gaussian), C1 = c1, C2 = c2.
+ * Replaces ssim() of src/func_util/ms_ssim.py:37-90 (fp32 there) and _SSIMForMultiScale of
+ * src/clic21/msssim.py:43-113 (fp64, fftconvolve 'valid'). */
+int aivc_ssim_means(const double *a, const double *b, int32_t n, int32_t h, int32_t w, const double *win,
+                    int32_t ws, double c1, double c2, double *workspace, double *out, aivc_stream_t stream);
+/* 2x2 mean to [n][ceil(h/2)][ceil(w/2)].  Odd sizes read one sample past the end: edge = 0 mirrors without
+ * repeating the border (ReflectionPad2d + avg_pool2d, src/func_util/ms_ssim.py:112-121), edge = 1 repeats it
+ * (scipy convolve mode='reflect' + [::2], src/clic21/msssim.py:173-175). */
+int aivc_pool2x2(const double *in, int32_t n, int32_t h, int32_t w, int32_t edge, double *out,
+                 aivc_stream_t stream);
+/* out[0] = sum (a[i] - b[i])^2 (src/clic21/metrics.py:58-59, src/model_mngt/loss_function.py:428-433). */
+int aivc_sq_err(const double *a, const double *b, size_t count, double *workspace, double *out,
+                aivc_stream_t stream);
 
 #ifdef __cplusplus
 }

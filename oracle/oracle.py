@@ -424,3 +424,34 @@ def run_layer(spec, x, res=None):
         return conv2d(att, pack_weight(spec['w_out']), spec['b_out'], act1=abi.ACT_SIGMOID,
                       mul=trunk, res=x)
     raise ValueError('unknown layer spec type %r' % t)
+
+
+# ---- quality metrics ---------------------------------------------------------------------------------
+def _f64(x):
+    return np.ascontiguousarray(np.asarray(x, np.float64))
+
+
+def ssim_means(a, b, win, c1, c2):
+    a, b, win = _f64(a), _f64(b), _f64(win)
+    n, h, w = a.shape
+    out = np.empty((n, 2), np.float64)
+    ws = np.empty(1024, np.float64)
+    _chk(lib()['aivc_ssim_means'](_p(a), _p(b), n, h, w, _p(win), len(win), float(c1), float(c2), _p(ws), _p(out), None),
+         'aivc_ssim_means')
+    return out
+
+
+def pool2x2(x, edge):
+    x = _f64(x)
+    n, h, w = x.shape
+    out = np.empty((n, (h + 1) // 2, (w + 1) // 2), np.float64)
+    _chk(lib()['aivc_pool2x2'](_p(x), n, h, w, int(edge), _p(out), None), 'aivc_pool2x2')
+    return out
+
+
+def sq_err(a, b):
+    a, b = _f64(a), _f64(b)
+    out = np.empty(1, np.float64)
+    ws = np.empty(1024, np.float64)
+    _chk(lib()['aivc_sq_err'](_p(a), _p(b), a.size, _p(ws), _p(out), None), 'aivc_sq_err')
+    return out

@@ -1,5 +1,7 @@
 """End-to-end parity on the GPU: HIP codec == CPU oracle codec (bitstream bytes and reconstructed
 frames), decoder == encoder reconstruction, batched level-synchronous schedule == frame by frame."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,3 +235,45 @@ def test_level_sharded_entry_point_single_rank(cuda):
         ref, _, dd = fc.encode_units(units, '1_GOP_4')
         got, dd2 = parallel.encode_units_level_sharded(fc, units, '1_GOP_4')
     assert got == ref and dd2['y'] == dd['y']
+
+
+def test_cli_encode_decode_evaluate(cuda, tmp_path, capsys):
+    """aivc.py end to end on a small clip: bitstream + decoded .yuv on disk, and the four evaluate.py lines
+    (CLIC PSNR / MS-SSIM computed on the GPU) equal to the CPU oracle's figures for the same two files."""
+    from aivc_amd import aivc as cli
+    from aivc_amd import synth
+    from oracle import metrics as ometrics
+    from oracle import oracle
+    w, h, n = 192, 128, 5
+    frames = synth.synthetic_video(w, h, n)
+    raw = tmp_path / ('clip_%dx%d_30_420.yuv' % (w, h))
+    with open(raw, 'wb') as f:
+        for fr in frames:
+            for k in 'yuv':
+                f.write(fr[k].tobytes())
+    out, bits = tmp_path / 'dec.yuv', tmp_path / 'bits.bin'
+    cli.main(['-i', str(raw), '--coding_config', 'RA', '--gop_size', '2', '--intra_period', '4', '--start_frame', '0',
+              '--end_frame', str(n - 1), '--bitstream_out', str(bits), '-o', str(out)])
+    printed = capsys.readouterr().out
+    fsz = h * w + 2 * (h // 2) * (w // 2)
+    dec = np.fromfile(out, np.uint8)
+    assert dec.size == n * fsz and os.path.getsize(bits) > 0
+    vals = {}
+    for line in printed.splitlines():
+        for key in ('PSNR    [dB]', 'MS-SSIM     ', 'MS-SSIM [dB]', 'Size [bytes]'):
+            if line.startswith(key + ':'):
+                vals[key] = float(line.split(':')[1])
+    assert set(vals) == {'PSNR    [dB]', 'MS-SSIM     ', 'MS-SSIM [dB]', 'Size [bytes]'}
+    assert vals['Size [bytes]'] == os.path.getsize(bits)
+    src = np.fromfile(raw, np.uint8).reshape(n, fsz).astype(np.float64)
+    dcd = dec.reshape(n, fsz).astype(np.float64)
+    num, sq, ms = 0, 0.0, 0.0
+    for i in range(n):
+        for lo, hi, shp in ((0, h * w, (h, w)), (h * w, h * w + fsz // 6, (h // 2, w // 2)), (h * w + fsz // 6, fsz, (h // 2, w // 2))):
+            a, b = src[i, lo:hi].reshape(1, *shp), dcd[i, lo:hi].reshape(1, *shp)
+            num += a.size
+            sq += oracle.sq_err(a, b)[0]
+            v = ometrics.msssim_clic(a, b) * a.size
+            ms += 0.0 if np.isnan(v) else v  # metrics.py:40-45: a NaN score counts as zero
+    assert abs(vals['PSNR    [dB]'] - (20 * np.log10(255.) - 10 * np.log10(sq / num))) < 1e-4  # 5 printed decimals
+    assert abs(vals['MS-SSIM     '] - ms / num) < 1e-5
