@@ -33,7 +33,8 @@ class FrameCodec:
     """max_batch bounds how many frames of one dependency level are pushed through the transforms
     together (activations of a 1080p frame at 1/2 resolution are 133 MB per 64-channel tensor)."""
 
-    def __init__(self, full_net, max_batch=8, entropy_chunk=64, entropy_streams=4, entropy_lookahead=2):
+    def __init__(self, full_net, max_batch=8, entropy_chunk=64, entropy_streams=4, entropy_lookahead=2,
+                 flag_md5sum=False):
         self.net = full_net
         self.entropy_chunk = entropy_chunk
         self.entropy_streams = max(2, entropy_streams)  # decoder: concurrent range-coder chains
@@ -41,6 +42,11 @@ class FrameCodec:
         self.mof = full_net.mode_net.mode_net
         self.cod = full_net.codec_net.codec_net
         self.max_batch = max_batch
+        # debug (src/real_life/bitstream.py:209-211): a feature-wise md5 in front of every section, checked by
+        # the decoder; both ends must agree on the flag (it is not signalled in the bitstream)
+        for net in (self.mof, self.cod):
+            if getattr(net, 'ac', None) is not None:
+                net.ac.flag_md5sum = bool(flag_md5sum)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod

@@ -26,8 +26,26 @@ class PendingSection:
     """A latent of ONE frame whose symbols are known on the device but not yet range-coded.
     q / sigma are [1,h,w,c] views; `flags` is that frame's row of a batched non-zero-map tensor."""
 
-    def __init__(self, mode, q, sigma=None, table=None, flags=None):
-        self.mode, self.q, self.sigma, self.table, self.flags = mode, q, sigma, table, flags
+    def __init__(self, mode, q, sigma=None, table=None, flags=None, md5=b''):
+        self.mode, self.q, self.sigma, self.table, self.flags, self.md5 = mode, q, sigma, table, flags, md5
+
+
+_MD5_LINES = None
+
+
+def latent_md5(q_nhwc):
+    """The 32 hex characters the reference puts in front of a section under flag_md5sum
+    (src/real_life/bitstream.py:229-234): md5 of the text file np.savetxt writes for the latent flattened in
+    NCHW order -- one '%.18e' line per symbol -- so a bitstream written with the flag by either code base
+    verifies under the other.  Debug path: the latent comes to the host (a sync)."""
+    global _MD5_LINES
+    import hashlib
+    if _MD5_LINES is None:
+        _MD5_LINES = [('%.18e\n' % v).encode() for v in range(-abi.AC_MAX_VAL - 1, abi.AC_MAX_VAL + 1)]
+    v = q_nhwc.permute(0, 3, 1, 2).to(torch.int16).cpu().numpy().astype(int).flatten()
+    lines = _MD5_LINES
+    off = abi.AC_MAX_VAL + 1
+    return hashlib.md5(b''.join([lines[x + off] for x in v.tolist()])).hexdigest().encode()
 
 
 def split_sections(frame_bytes):
@@ -160,13 +178,14 @@ def launch_finalize(frames_sections, side_stream=None, prepared=None, fork_strea
         jobs, bounds = [], []
         for j, (fi, si, s) in enumerate(lap):
             maps = [int(c) for c in np.nonzero(flags_h[j])[0]]
-            heads[fi][si] = bytes([len(maps)]) + bytes(maps)
+            heads[fi][si] = s.md5 + bytes([len(maps)]) + bytes(maps)
             if maps:
                 jobs.append((fi, si))
                 bounds.append(ops.laplace_bounds(s.sigma, s.q, maps))
         for fi, secs in enumerate(frames_sections):
             for si, s in enumerate(secs):
                 if s is not None and s.mode == 'pmf':
+                    heads[fi][si] = s.md5
                     jobs.append((fi, si))
                     bounds.append(ops.table_bounds(s.table, s.q))
         out_h = lens_h = offs = event = None
@@ -196,8 +215,11 @@ def finalize_frame(sections):
 
 class ArithmeticCoder():
     def __init__(self, param):
-        default = {'balle_pdf_estim_z': None, 'device': 'cpu', 'AC_MAX_VAL': abi.AC_MAX_VAL}
+        default = {'balle_pdf_estim_z': None, 'device': 'cpu', 'AC_MAX_VAL': abi.AC_MAX_VAL, 'flag_md5sum': False}
         self.balle_pdf_estim = get_value('balle_pdf_estim_z', param, default)
+        # debug: prepend / verify the reference's feature-wise md5 on every section (bitstream.py:26-49)
+        self.flag_md5sum = get_value('flag_md5sum', param, default)
+        self.md5_errors = []
         self.AC_MAX_VAL = get_value('AC_MAX_VAL', param, default)
         if self.AC_MAX_VAL != abi.AC_MAX_VAL:
             raise NotImplementedError('the kernels are built for AC_MAX_VAL = %d' % abi.AC_MAX_VAL)
@@ -218,23 +240,47 @@ class ArithmeticCoder():
     def pend_z(self, q_z):
         """q_z [n,h,w,c] -> list of n PendingSection"""
         table = self.z_table(q_z.device)
-        return [PendingSection('pmf', q_z[i:i + 1], table=table) for i in range(q_z.shape[0])]
+        return [PendingSection('pmf', q_z[i:i + 1], table=table, md5=self._md5(q_z[i:i + 1]))
+                for i in range(q_z.shape[0])]
 
     def pend_y(self, q_y, sigma):
         flags = ops.nonzero_flags(q_y)  # async, no sync here
-        return [PendingSection('laplace', q_y[i:i + 1], sigma=sigma[i:i + 1], flags=flags[i])
+        return [PendingSection('laplace', q_y[i:i + 1], sigma=sigma[i:i + 1], flags=flags[i], md5=self._md5(q_y[i:i + 1]))
                 for i in range(q_y.shape[0])]
+
+    def _md5(self, q):
+        return latent_md5(q) if self.flag_md5sum else b''
+
+    def _strip_md5(self, payloads):
+        if not self.flag_md5sum:
+            return payloads, None
+        return [p[32:] for p in payloads], [p[:32] for p in payloads]
+
+    def _check_md5(self, q, sums, what):
+        """bitstream.py:488-499: report, do not raise"""
+        if sums is None:
+            return
+        for i, want in enumerate(sums):
+            if latent_md5(q[i:i + 1]) != want:
+                self.md5_errors.append((what, i))
+                print('[Error] lossy arithmetic coding for')
+                print('\t%s frame %d of the batch' % (what, i))
+                print('-' * 80)
 
     def decode_z(self, payloads, h, w, c, device):
         """list of n payloads -> q_z int16 NHWC [n,h,w,c] (pmf mode, all channels); the n streams
         are decoded concurrently."""
+        payloads, sums = self._strip_md5(payloads)
         n, npix = len(payloads), h * w
         syms = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n)
         maps = list(range(c))
-        return torch.stack([ops.scatter_symbols(s, npix, c, maps).view(h, w, c) for s in syms])
+        q = torch.stack([ops.scatter_symbols(s, npix, c, maps).view(h, w, c) for s in syms])
+        self._check_md5(q, sums, 'z latent')
+        return q
 
     def decode_y(self, payloads, sigma):
         """list of n payloads + sigma [n,h,w,c] -> q_y int16 [n,h,w,c] (zero maps restored)."""
+        payloads, sums = self._strip_md5(payloads)
         n, h, w, c = sigma.shape
         npix = h * w
         maps = [list(p[1:1 + p[0]]) for p in payloads]
@@ -251,7 +297,9 @@ class ArithmeticCoder():
             dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], rows,
                                    [row_offs[i] for i in live], [len(maps[i]) * npix for i in live], [0] * len(live))
             syms = dict(zip(live, dec))
-        return torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
+        q = torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
+        self._check_md5(q, sums, 'y latent')
+        return q
 
     # ---- path-based API with the reference's signatures (NCHW float tensors, one file per frame) --
     def encode(self, param):
@@ -262,12 +310,14 @@ class ArithmeticCoder():
         sigma = get_value('sigma', param, default)
         path = get_value('bitstream_path', param, default)
         latent_name = get_value('latent_name', param, default)
-        if get_value('flag_md5sum', param, default):
-            raise NotImplementedError('flag_md5sum debug sections are not implemented')
         if not path.endswith(BITSTREAM_SUFFIX):
             path += BITSTREAM_SUFFIX
         q = ops.to_nhwc(x).to(torch.int16)
-        sec = (self.pend_y(q, ops.to_nhwc(sigma)) if mode == 'laplace' else self.pend_z(q))[0]
+        keep, self.flag_md5sum = self.flag_md5sum, bool(get_value('flag_md5sum', param, default))
+        try:
+            sec = (self.pend_y(q, ops.to_nhwc(sigma)) if mode == 'laplace' else self.pend_z(q))[0]
+        finally:
+            self.flag_md5sum = keep
         slots = [None] * 4
         slots[SECTION_NAMES.index(latent_name)] = sec
         body = split_sections(finalize_frame(slots))[SECTION_NAMES.index(latent_name)]
@@ -290,9 +340,16 @@ class ArithmeticCoder():
             path += BITSTREAM_SUFFIX
         with open(path, 'rb') as f:
             payload = split_sections(f.read())[SECTION_NAMES.index(latent_name)]
-        if mode == 'laplace':
-            q = self.decode_y([payload], ops.to_nhwc(sigma))
-        else:
-            b, c, h, w = data_dim
-            q = self.decode_z([payload], h, w, c, torch.device(device))
+        keep, self.flag_md5sum = self.flag_md5sum, bool(get_value('flag_md5sum', param, default))
+        try:
+            n_err = len(self.md5_errors)
+            if mode == 'laplace':
+                q = self.decode_y([payload], ops.to_nhwc(sigma))
+            else:
+                b, c, h, w = data_dim
+                q = self.decode_z([payload], h, w, c, torch.device(device))
+            if self.flag_md5sum and len(self.md5_errors) == n_err:
+                print('All good for ' + path + ' ' + latent_name)
+        finally:
+            self.flag_md5sum = keep
         return ops.to_nchw_view(q.float())

@@ -277,3 +277,38 @@ def test_cli_encode_decode_evaluate(cuda, tmp_path, capsys):
             ms += 0.0 if np.isnan(v) else v  # metrics.py:40-45: a NaN score counts as zero
     assert abs(vals['PSNR    [dB]'] - (20 * np.log10(255.) - 10 * np.log10(sq / num))) < 1e-4  # 5 printed decimals
     assert abs(vals['MS-SSIM     '] - ms / num) < 1e-5
+
+
+def test_md5_debug_sections(cuda):
+    """flag_md5sum: every present section grows by the 32-byte digest, the rest of the bytes is unchanged, the
+    decoder verifies silently; a corrupted digest is reported (and decoding still completes, as in the reference)."""
+    from aivc_amd import synth
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.models import arch
+    from aivc_amd.real_life.bitstream import split_sections
+    from aivc_amd.real_life import cat_binary_files as cont
+    model = synth.make_model(arch.TINY_WIDTHS, seed=11, device=cuda)
+    frames = synth.to_device_frames(synth.synthetic_video(64, 48, 3), cuda)
+    plain = FrameCodec(model)
+    blob0, rec0, dd = plain.encode_gop(frames, '1_GOP_2')
+    dbg = FrameCodec(model, flag_md5sum=True)
+    try:
+        blob1, rec1, _ = dbg.encode_gop(frames, '1_GOP_2')
+        f0, f1 = cont.unpack_gop(blob0)[2], cont.unpack_gop(blob1)[2]
+        for a, b in zip(f0, f1):
+            for sa, sb in zip(split_sections(a), split_sections(b)):
+                assert (len(sa) == 0 and len(sb) == 0) or (sb[32:] == sa and len(sb[:32].decode()) == 32)
+        out = dbg.decode_gop(blob1, dd)
+        assert not dbg.cod.ac.md5_errors and not dbg.mof.ac.md5_errors
+        for a, b in zip(out, rec1):
+            for k in 'yuv':
+                assert torch.equal(a[k], b[k])
+        # flip one hex digit of the first digest of the I frame
+        head, fr = blob1[:blob1.index(f1[0])], bytearray(f1[0])
+        pos = 8 + 4  # two empty MOFNet sections (4-byte zero lengths), then codecnet_z's length word
+        fr[pos] = ord('0') if fr[pos] != ord('0') else ord('1')
+        bad = blob1.replace(bytes(f1[0]), bytes(fr), 1)
+        dbg.decode_gop(bad, dd)
+        assert dbg.cod.ac.md5_errors == [('z latent', 0)]
+    finally:
+        dbg.cod.ac.flag_md5sum = dbg.mof.ac.flag_md5sum = False

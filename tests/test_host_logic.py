@@ -122,3 +122,20 @@ def test_section_framing_without_gpu():
     from aivc_amd.real_life.bitstream import split_sections
     frame = (0).to_bytes(4, 'big') * 2 + (3).to_bytes(4, 'big') + b'abc' + (1).to_bytes(4, 'big') + b'\x00'
     assert split_sections(frame) == [b'', b'', b'abc', b'\x00']
+
+
+def test_md5_debug_digest_is_the_reference_procedure(tmp_path):
+    """flag_md5sum (src/real_life/bitstream.py:229-234): md5 of the np.savetxt text of the NCHW-flattened latent"""
+    import hashlib
+
+    import numpy as np
+    import torch
+    from aivc_amd.real_life.bitstream import latent_md5
+    rng = np.random.default_rng(3)
+    q = torch.from_numpy(rng.integers(-256, 256, (1, 5, 7, 3)).astype(np.int16))  # NHWC
+    q[0, 0, 0, 0], q[0, 0, 0, 1] = -256, 255
+    x_nchw = q.permute(0, 3, 1, 2).to(torch.int16).numpy().astype(int)
+    path = tmp_path / 'tmp_tensor.npy'
+    np.savetxt(path, x_nchw.flatten())
+    want = hashlib.md5(open(path, 'rb').read()).hexdigest().encode()
+    assert latent_md5(q) == want and len(want) == 32
