@@ -162,3 +162,52 @@ def encode_units_level_sharded(frame_codec, units, gop_name, idx_rate=0., comm_d
     head = hdr.gop_header_bytes(gop_name, idx_rate)
     blobs = [container.pack_gop(head, [fbytes[u][f] for f in names]) for u in range(len(units))]
     return blobs, data_dim
+
+
+def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, comm_device=None):
+    """Like FrameCodec.decode_units for ONE GOP structure, with the frames of every dependency level
+    distributed round-robin over the ranks (clips with fewer intra-period units than GPUs: configs[3] on 8
+    GPUs, configs[4]).  Every rank passes the same blobs and returns the same reconstructions; the only
+    exchange is one all_gather of the new 8-bit frames per level (they are the references of the next)."""
+    from .codec import frame_index
+    from .func_util.GOP_structure import coding_levels, generate_gop_struct
+    from .real_life import cat_binary_files as container
+    rank, world = rank_world()
+    parsed = [container.unpack_gop(g) for g in gop_blobs]
+    gop_name, idx_rate = parsed[0][0], parsed[0][1]
+    if any((p[0], p[1]) != (gop_name, idx_rate) for p in parsed):
+        raise ValueError('decode_units_level_sharded: all units must share one GOP structure and rate index')
+    gop = generate_gop_struct(gop_name)
+    names = sorted(gop, key=frame_index)
+    h, w = data_dim['x']
+    rec = [dict() for _ in gop_blobs]
+    dev = device
+    for level in coding_levels(gop):
+        for ftype in sorted({gop[f]['type'] for f in level}):
+            items = [(u, f) for u in range(len(gop_blobs)) for f in level if gop[f]['type'] == ftype]
+            mine = items[rank::world]
+            my_recs = []
+            for s in range(0, len(mine), frame_codec.max_batch):
+                chunk = mine[s:s + frame_codec.max_batch]
+                my_recs += frame_codec.decode_batch([parsed[u][2][frame_index(f)] for u, f in chunk],
+                                                    [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
+                                                    [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, data_dim,
+                                                    idx_rate, device)
+            if my_recs and dev is None:
+                dev = my_recs[0]['y'].device
+            if world == 1:
+                all_recs = [my_recs]
+            else:
+                cdev = comm_device or dev or torch.device('cpu')
+                per = (len(items) + world - 1) // world
+                fsz = h * w + 2 * ((h + 1) // 2) * ((w + 1) // 2)
+                send = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
+                if my_recs:
+                    send[:len(my_recs)] = _frames_to_tensor(my_recs, cdev)
+                gathered = [torch.empty_like(send) for _ in range(world)]
+                dist.all_gather(gathered, send)
+                all_recs = [_tensor_to_frames(g[:len(items[r::world])], h, w, dev or cdev) for r, g in enumerate(gathered)]
+            for r in range(world):
+                for (u, f), rc in zip(items[r::world], all_recs[r]):
+                    rec[u][f] = rc
+    return [[rec[u][f] for f in names] for u in range(len(gop_blobs))]

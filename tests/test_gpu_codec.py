@@ -235,6 +235,13 @@ def test_level_sharded_entry_point_single_rank(cuda):
         ref, _, dd = fc.encode_units(units, '1_GOP_4')
         got, dd2 = parallel.encode_units_level_sharded(fc, units, '1_GOP_4')
     assert got == ref and dd2['y'] == dd['y']
+    with torch.no_grad():
+        want = fc.decode_units(ref, dd)
+        have = parallel.decode_units_level_sharded(fc, ref, dd)
+    for ua, ub in zip(want, have):
+        for a, b in zip(ua, ub):
+            for k in 'yuv':
+                assert torch.equal(a[k], b[k])
 
 
 def test_cli_encode_decode_evaluate(cuda, tmp_path, capsys):

@@ -108,6 +108,17 @@ class OracleFrameCodec:
             secs.append(fb)
         return {'sections': secs, 'rec': recs, 'data_dim': dict(dd, x_uv=None)}
 
+    def decode_batch(self, frames_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
+        from oracle import codec as oc
+
+        def np_planes(p):
+            return None if p is None else {k: p[k][0].numpy() for k in 'yuv'}
+        out = []
+        for fb, p, n in zip(frames_bytes, prev, nxt):
+            rec = oc.decode_frame(self.spec, fb, np_planes(p), np_planes(n), frame_type, data_dim, idx_rate)
+            out.append({k: torch.from_numpy(np.ascontiguousarray(rec[k])).unsqueeze(0) for k in 'yuv'})
+        return out
+
 
 def _worker_levels(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -149,3 +160,48 @@ def test_temporal_level_sharding_matches_single_process(oracle):
     assert oc.split_lp(ref, 18, 2) == res[0][1]
     assert (res[0][2], res[0][3], res[0][4]) == ((32, 48), tuple(int.from_bytes(ref[i:i + 2], 'big') for i in (4, 6)),
                                                   tuple(int.from_bytes(ref[i:i + 2], 'big') for i in (8, 10)))
+
+
+def _worker_levels_decode(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from aivc_amd import parallel, synth
+    from aivc_amd.models import arch
+    from oracle import codec as oc
+    from oracle import spec as ospec
+    model = synth.make_model(arch.TINY_WIDTHS, seed=100)
+    spec = ospec.export_model(model)
+    blob, _ = oc.encode_video(spec, synth.synthetic_video(48, 32, 10, seed=2), '1_GOP_4')
+    gops = oc.split_lp(blob, 18, 2)
+    dd = {'x': (32, 48), 'y': tuple(int.from_bytes(blob[i:i + 2], 'big') for i in (4, 6)),
+          'z': tuple(int.from_bytes(blob[i:i + 2], 'big') for i in (8, 10))}
+    recs = parallel.decode_units_level_sharded(OracleFrameCodec(spec), gops, dd, comm_device=torch.device('cpu'))
+    digest = [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).numpy()) for unit in recs for fr in unit]
+    q.put((rank, digest))
+    dist.destroy_process_group()
+
+
+def test_temporal_level_sharded_decode_matches_single_process(oracle):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_levels_decode, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]  # every rank ends with the same frames
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from oracle import codec as oc
+    from oracle import spec as ospec
+    spec = ospec.export_model(synth.make_model(arch.TINY_WIDTHS, seed=100))
+    blob, _ = oc.encode_video(spec, synth.synthetic_video(48, 32, 10, seed=2), '1_GOP_4')
+    frames = oc.decode_video(spec, blob)
+    want = [bytes(np.concatenate([np.asarray(fr[k]).reshape(-1) for k in 'yuv'])) for fr in frames]
+    assert res[0][1] == want
