@@ -132,7 +132,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     e0.record()
     call('aivc_conv2d', C.byref(p), _stream())
     e1.record()
-    PROFILE.append((variant, flops, e0, e1))
+    PROFILE.append((variant, flops, e0, e1, (mode, k, stride, c_real, co, n, h, w_, gdn is not None)))
     return y
 
 

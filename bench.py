@@ -205,11 +205,20 @@ def main():
         step(n_total - 1)
         torch.cuda.synchronize()
         per = {}
-        for variant, flops, e0, e1 in ops.PROFILE:
-            d = per.setdefault(variant, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += flops
-            d[2] += e0.elapsed_time(e1) * 1e-3
+        shapes = {}
+        for variant, flops, e0, e1, shape in ops.PROFILE:
+            sec_ = e0.elapsed_time(e1) * 1e-3
+            for table, key in ((per, variant), (shapes, (variant,) + shape)):
+                d = table.setdefault(key, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += flops
+                d[2] += sec_
+        if os.environ.get('AIVC_LAYER_TABLE'):  # tuning aid: per-layer-shape time of one step, on stderr
+            for key, d in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+                v, mode, k, st, ci, co, nb, hh, ww, g = key
+                sys.stderr.write('%8.2f ms %5d x  %6.1f TF/s  %-30s mode%d k%d s%d %3d->%3d%s n%d %dx%d\n' % (
+                    d[2] * 1e3, d[0], d[1] / d[2] / 1e12, VARIANT_NAMES.get(v, str(v)), mode, k, st, ci, co,
+                    '+gdn' if g else '', nb, hh, ww))
         ops.PROFILE = None
         mf = {v: d for v, d in per.items() if v >= 100}
         if mf:

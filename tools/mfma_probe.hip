@@ -117,10 +117,25 @@ __global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             f4 af[2], bf[2];
+            if (FEAT & 16) {
+                // unpermuted rows: lane half h reads k = h, 2 + h, 4 + h, 6 + h of the octet (two ds_read2_b32)
+                const int hh = lane >> 5;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float* q = a_frag - hh * 4 + hh + i * 32 * STRIDE + o * 8;
+                    af[i] = (f4){q[0], q[2], q[4], q[6]};
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float* q = b_frag - hh * 4 + hh + j * 32 * STRIDE + o * 8;
+                    bf[j] = (f4){q[0], q[2], q[4], q[6]};
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f4*>(a_frag + i * 32 * STRIDE + o * 8);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f4*>(b_frag + j * 32 * STRIDE + o * 8);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -266,7 +281,9 @@ int main() {
         printf(", \"+barriers+ds_write+perm\": %.1f", run_lds<11>(out, din, big, mask, cus, e0, e1));
         printf(", \"+global_loads\": %.1f", run_lds<4>(out, din, big, mask, cus, e0, e1));
         printf(", \"+barriers+ds_write+global_loads\": %.1f", run_lds<7>(out, din, big, mask, cus, e0, e1));
-        printf(", \"all\": %.1f}", run_lds<15>(out, din, big, mask, cus, e0, e1));
+        printf(", \"all\": %.1f", run_lds<15>(out, din, big, mask, cus, e0, e1));
+        printf(", \"mfma_only_read2\": %.1f", run_lds<16>(out, din, big, mask, cus, e0, e1));
+        printf(", \"all_noperm_read2\": %.1f}", run_lds<16 + 7>(out, din, big, mask, cus, e0, e1));
     }
     // order check
     const int steps = 16, trials = 200;
