@@ -199,6 +199,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # quality of what was coded (outside the timed region; on-device CLIC metrics, aivc_amd/clic21): first
+    # intra-period unit of the first timed clip.  With the synthetic random-init weights the figures say nothing
+    # about the codec's rate-distortion -- they are the "PSNR/bpp" slots of the metric, filled by the same code
+    # that would score real weights.
+    quality = None
+    if rank == 0 and not os.environ.get('AIVC_NO_QUALITY'):
+        from aivc_amd.clic21.metrics import evaluate
+        with torch.no_grad():
+            q_enc = fc.encode_video(clips[args.warmup][:unit], args.gop)
+            q_blob = fc.assemble_video(q_enc)
+            q_dec, _, _, _ = fc.decode_video(q_blob, dev)
+        target, submit = {}, {}
+        for i, (src, d) in enumerate(zip(clips[args.warmup][:unit], q_dec)):
+            for k in 'yuv':
+                target['%d_%s' % (i, k)] = src[k]
+                submit['%d_%s' % (i, k)] = d[k]
+        r = evaluate(submit, target)
+        quality = {'frames': unit, 'psnr_db': round(float(r['PSNR']), 4), 'ms_ssim': round(float(r['MSSSIM']), 6),
+                   'bpp': round(len(q_blob) * 8.0 / (unit * args.width * args.height), 5),
+                   'note': 'synthetic random-init weights: not a rate-distortion result'}
+
     roofline = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
@@ -266,7 +287,7 @@ def main():
             'encode_fps_rank0': round(args.steps * per_step / stats['enc_s'], 3),
             'decode_fps_rank0': round(args.steps * per_step / stats['dec_s'], 3),
             'bytes_per_frame': round(stats['bytes'] / (args.steps * per_step), 1),
-            'closed_loop_ok': bool(closed_loop),
+            'closed_loop_ok': bool(closed_loop), 'quality': quality,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if args.tiny:

@@ -13,6 +13,8 @@ SHAPES = [  # name, mode, k, s, pad, cin, cout, h_in, w_in
     ('cheng conv3s2 128 @270p', abi.MODE_CONV, 3, 2, 1, 128, 128, 270, 480),
     ('cheng conv3 128 @135p', abi.MODE_CONV, 3, 1, 1, 128, 128, 135, 240),
     ('att 1x1 128->64 @135p', abi.MODE_CONV, 1, 1, 0, 128, 64, 135, 240),
+    ('res 1x1 64->128 @135p', abi.MODE_CONV, 1, 1, 0, 64, 128, 135, 240),
+    ('res 1x1 128->128 @135p', abi.MODE_CONV, 1, 1, 0, 128, 128, 135, 240),
     ('att 3x3 64->64 @135p', abi.MODE_CONV, 3, 1, 1, 64, 64, 135, 240),
     ('ga4 conv5s2 128->64 @135p', abi.MODE_CONV, 5, 2, 2, 128, 64, 135, 240),
     ('res 3x3 128 @68p', abi.MODE_CONV, 3, 1, 1, 128, 128, 68, 120),

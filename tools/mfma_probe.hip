@@ -80,7 +80,21 @@ __global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float* dst = smem + ((tid + 256 * u) >> 2) * STRIDE + ((tid + 256 * u) & 3) * 8;
-                if (FEAT & 8) {
+                if (FEAT & 32) {
+                    // same permutation with v_pk_mov_b32: two dwords per instruction
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 a01 = {st[u][0][0], st[u][0][1]}, a23 = {st[u][0][2], st[u][0][3]};
+                    f2 b01 = {st[u][1][0], st[u][1][1]}, b23 = {st[u][1][2], st[u][1][3]};
+                    f2 l0, l1, h0, h1;
+                    asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(l0) : "v"(a01), "v"(a23));
+                    asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(l1) : "v"(b01), "v"(b23));
+                    asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(h0) : "v"(a01), "v"(a23));
+                    asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(h1) : "v"(b01), "v"(b23));
+                    f4 lo = {l0[0], l0[1], l1[0], l1[1]};
+                    f4 hi = {h0[0], h0[1], h1[0], h1[1]};
+                    *reinterpret_cast<f4*>(dst) = lo;
+                    *reinterpret_cast<f4*>(dst + 4) = hi;
+                } else if (FEAT & 8) {
                     f4 lo = {st[u][0][0], st[u][0][2], st[u][1][0], st[u][1][2]};
                     f4 hi = {st[u][0][1], st[u][0][3], st[u][1][1], st[u][1][3]};
                     *reinterpret_cast<f4*>(dst) = lo;
@@ -282,6 +296,7 @@ int main() {
         printf(", \"+global_loads\": %.1f", run_lds<4>(out, din, big, mask, cus, e0, e1));
         printf(", \"+barriers+ds_write+global_loads\": %.1f", run_lds<7>(out, din, big, mask, cus, e0, e1));
         printf(", \"all\": %.1f", run_lds<15>(out, din, big, mask, cus, e0, e1));
+        printf(", \"all_pk_mov\": %.1f", run_lds<7 + 32>(out, din, big, mask, cus, e0, e1));
         printf(", \"mfma_only_read2\": %.1f", run_lds<16>(out, din, big, mask, cus, e0, e1));
         printf(", \"all_noperm_read2\": %.1f}", run_lds<16 + 7>(out, din, big, mask, cus, e0, e1));
     }
