@@ -157,11 +157,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       const float *src = p.x + ((a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(ci0 + ((tid + 256 * j) % OCT) * 8));
       float4 v0 = *reinterpret_cast<const float4 *>(src);
       float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-      if (TCONV) {
-        const float z = ok ? 1.0f : 0.0f;  // select, not multiply: avoids NaN * 0
+      if (TCONV) {  // select, not multiply by 0/1: avoids NaN * 0
         v0 = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
         v1 = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
-        (void)z;
       }
       if (GDN) {
         v0.x *= v0.x; v0.y *= v0.y; v0.z *= v0.z; v0.w *= v0.w;

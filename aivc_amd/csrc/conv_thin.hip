@@ -83,8 +83,6 @@ __global__ __launch_bounds__(TH * 16) void thin_tconv_kernel(aivc_conv_params p)
 #pragma unroll
       for (int c = c0; c < c0 + PAR; ++c) {
         const int pyc = c >> 1, pxc = c & 1;
-        constexpr int dummy = 0;
-        (void)dummy;
         const int nx = class_ntaps<KS>(pxc);
         if (t < class_ntaps<KS>(pyc) * nx) {
           const int ky = class_tap<KS>(pyc, t / nx), kx = class_tap<KS>(pxc, t % nx);

@@ -326,6 +326,44 @@ class ArithmeticCoder():
             blob = (0).to_bytes(8, 'big') + blob
         with open(path, 'ab') as f:
             f.write(blob)
+        if get_value('flag_debug', param, default):
+            self._debug_report(x, sigma, mode, body, len(blob), path, latent_name, param)
+
+    def _debug_report(self, x, sigma, mode, body, nbytes_written, path, latent_name, param):
+        """flag_debug of the reference (src/real_life/bitstream.py:306-350): estimated against real rate, then
+        a decode of what was just written.  Debug path: plain torch on the device, one sync."""
+        md5 = 32 if param.get('flag_md5sum', False) else 0
+        if mode == 'laplace':
+            nb_sent = body[md5]
+            header_overhead = md5 + 1 + nb_sent
+            b = sigma / torch.sqrt(torch.tensor([2.0], device=x.device))
+            pdf = torch.distributions.Laplace(torch.zeros_like(b), b)
+            proba = torch.clamp(pdf.cdf(x + 0.5) - pdf.cdf(x - 0.5), 2 ** -16, 1.)
+        else:
+            nb_sent = x.shape[1]
+            header_overhead = md5
+            _, cdf = self.balle_pdf_estim.cdf_table(x.device, want_float=True)  # [C, 514] at k - 256.5
+            idx = (x.long() + self.AC_MAX_VAL)[0]  # [C, h, w]
+            c = cdf.reshape(x.shape[1], abi.LP)
+            ar = torch.arange(x.shape[1], device=x.device)[:, None, None]
+            proba = torch.clamp(c[ar, idx + 1] - c[ar, idx], 2 ** -16, 1.)
+        estimated_rate = (-torch.log2(proba).sum() / 8000).item() + 1e-3
+        real_rate = (len(body) + 4) / 1000
+        print('Arithmetic coding of      : ' + str(path.split('/')[-1].rstrip(BITSTREAM_SUFFIX)) + ' ' + latent_name)
+        print('Number of ft. maps sent   : ' + str(nb_sent))
+        print('Bitrate estimation [kByte]: ' + '%.3f' % estimated_rate)
+        print('Real bitstream     [kByte]: ' + '%.3f' % real_rate)
+        print('Rate overhead          [%]: ' + '%.1f' % ((real_rate / estimated_rate - 1) * 100))
+        print('Absolute overhead  [Kbyte]: ' + '%.3f' % (real_rate - estimated_rate))
+        print('Header overhead     [byte]: ' + '%.1f' % header_overhead)
+        print('Nb. bytes in file   [byte]: ' + '%.1f' % nbytes_written)
+        x_decoded = self.decode(dict(param, data_dim=x.size(), device=x.device, flag_debug=False))
+        if torch.all(torch.eq(x, x_decoded.to(x.dtype))):
+            print('Ok! Entropy coding is lossless\n')
+        else:
+            print('-' * 80)
+            print('Ko! Entropy coding is not lossless: ' + str((x_decoded - x).abs().sum()) + '\n')
+            print('-' * 80)
 
     def decode(self, param):
         default = {'mode': 'laplace', 'sigma': None, 'bitstream_path': None, 'data_dim': None, 'device': 'cpu',

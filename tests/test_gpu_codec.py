@@ -319,3 +319,33 @@ def test_md5_debug_sections(cuda):
         assert dbg.cod.ac.md5_errors == [('z latent', 0)]
     finally:
         dbg.cod.ac.flag_md5sum = dbg.mof.ac.flag_md5sum = False
+
+
+def test_path_api_debug_flags(cuda, tmp_path, capsys):
+    """ArithmeticCoder.encode / decode with the reference's signature (one .bin file per frame, sections
+    appended), flag_debug (rate report + decode-back check) and flag_md5sum both on"""
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    model = synth.make_model(arch.TINY_WIDTHS, seed=21, device=cuda)
+    ac = model.codec_net.codec_net.ac
+    g = torch.Generator(device=cuda).manual_seed(3)
+    c_z, c_y = arch.TINY_WIDTHS['c_z'], arch.TINY_WIDTHS['c_y']
+    z = torch.randint(-3, 4, (1, c_z, 5, 7), generator=g, device=cuda).float()
+    y = torch.randint(-6, 7, (1, c_y, 9, 13), generator=g, device=cuda).float()
+    y[:, 1] = 0  # an all-zero feature map is skipped by the bitstream
+    sigma = torch.rand((1, c_y, 9, 13), generator=g, device=cuda) * 3 + 0.3
+    path = str(tmp_path / '0')
+    ac.encode({'x': z, 'mode': 'pmf', 'bitstream_path': path, 'latent_name': 'codecnet_z', 'flag_md5sum': True})
+    ac.encode({'x': y, 'mode': 'laplace', 'sigma': sigma, 'bitstream_path': path, 'latent_name': 'codecnet_y',
+               'flag_md5sum': True})
+    out = capsys.readouterr().out
+    assert out.count('Ok! Entropy coding is lossless') == 2 and 'Ko!' not in out
+    assert 'Number of ft. maps sent   : %d' % (c_y - 1) in out and 'Number of ft. maps sent   : %d' % c_z in out
+    zd = ac.decode({'mode': 'pmf', 'bitstream_path': path, 'data_dim': z.size(), 'device': cuda,
+                    'latent_name': 'codecnet_z', 'flag_md5sum': True})
+    yd = ac.decode({'mode': 'laplace', 'sigma': sigma, 'bitstream_path': path, 'data_dim': y.size(), 'device': cuda,
+                    'latent_name': 'codecnet_y', 'flag_md5sum': True})
+    assert torch.equal(zd, z) and torch.equal(yd, y)
+    assert capsys.readouterr().out.count('All good for') == 2 and not ac.md5_errors
+    raw = open(path, 'rb').read()
+    assert raw[:8] == bytes(8)  # the two empty MOFNet sections of an I frame
