@@ -168,6 +168,83 @@ __global__ __launch_bounds__(256, 2) void peak32_lds(float* out, const float* in
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Candidate K loop without register staging: v_mfma_f32_32x32x1_2b_f32 (K = 1 per instruction, the two lane halves
+// are two 32-row blocks of the M tile sharing B) needs NO K permutation -- every lane consumes 4 consecutive k from one
+// ds_read_b128 of the natural row-major layout -- so tiles can go global -> LDS directly (global_load_lds_dwordx4,
+// lane-linear destination; bank conflicts avoided by an XOR swizzle of the 16-byte quad index with the row, applied
+// to the SOURCE address and to the read), double-buffered, one barrier per K-tile.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void peak32_dlds(float* out, int iters, const float* big) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 256 * 36];  // 2 buffers x (128 A rows + 128 B rows) x 32 k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned npix = 8u * 135u * 240u;
+    f16v acc[2][2];  // [n half][block pair as one 32-register accumulator split in two]
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typedef float f32v __attribute__((ext_vector_type(32)));
+    f32v c0, c1;
+    for (int r = 0; r < 32; ++r) c0[r] = 0.f, c1[r] = 0.f;
+
+    // per-slot constants: this thread's 8 (row, quad) slots of a tile; waves 0-1 stage A rows, waves 2-3 B rows
+    int s_pix[8], s_q[8];
+    const float* s_w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int slot = (wave * 8 + i) * 64 + lane;
+        const int row = slot >> 3;
+        s_q[i] = ((slot & 7) ^ (row & 7)) * 4;
+        s_pix[i] = row;
+        s_w[i] = big + (size_t)npix * 128 + (size_t)(row & 127) * 1152 + s_q[i];
+    }
+    auto issue = [&](int it, int buf) {
+        const int kt = it % 36, tap = kt >> 2, chunk = kt & 3;
+        const int tile = (int)((blockIdx.x + (unsigned)(it / 36) * gridDim.x) % (npix / 128u));
+        const int toff = tile * 128 + (tap / 3 - 1) * 240 + (tap % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* src;
+            if (wave < 2) {  // wave-uniform
+                int pix = s_pix[i] + toff;
+                pix = pix < 0 ? 0 : (pix >= (int)npix ? (int)npix - 1 : pix);
+                src = big + (size_t)pix * 128 + chunk * 32 + s_q[i];
+            } else {
+                src = s_w[i] + kt * 32;
+            }
+            float* dst = smem + buf * (256 * 32) + (wave * 8 + i) * 256;  // wave-uniform base, + lane * 16 B implicit
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    __syncthreads();
+    const int a_row = wm * 64 + lane;
+    const int b_row0 = 128 + wn * 64 + (lane & 31);
+    for (int it = 0; it < iters; ++it) {
+        const int cur = it & 1;
+        if (MODE & 1) issue(it + 1, cur ^ 1);
+        const float* base = smem + cur * (256 * 32);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int oa = (MODE & 4) ? o : (o ^ (a_row & 7)), ob = (MODE & 4) ? o : (o ^ (b_row0 & 7));
+            const f4 a4 = *reinterpret_cast<const f4*>(base + a_row * ((MODE & 4) ? 36 : 32) + (oa << 2));
+            const f4 b0 = *reinterpret_cast<const f4*>(base + b_row0 * ((MODE & 4) ? 36 : 32) + (ob << 2));
+            const f4 b1 = *reinterpret_cast<const f4*>(base + (b_row0 + 32) * ((MODE & 4) ? 36 : 32) + (ob << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a4[e], b0[e], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a4[e], b1[e], c1, 0, 0, 0);
+            }
+        }
+        if (MODE & 2) __syncthreads();
+        asm volatile("" ::: "memory");
+    }
+    float s = 0.f;
+    for (int r = 0; r < 32; ++r) s += c0[r] + c1[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + acc[0][0][0];
+}
+
 template <int FEAT>
 static double run_lds(float* out, const float* din, const float* big, unsigned mask, int cus, hipEvent_t e0, hipEvent_t e1) {
     float ms;
@@ -297,6 +374,24 @@ int main() {
         printf(", \"+barriers+ds_write+global_loads\": %.1f", run_lds<7>(out, din, big, mask, cus, e0, e1));
         printf(", \"all\": %.1f", run_lds<15>(out, din, big, mask, cus, e0, e1));
         printf(", \"all_pk_mov\": %.1f", run_lds<7 + 32>(out, din, big, mask, cus, e0, e1));
+        {
+            auto run = [&](auto kern) {
+                float ms;
+                const int it = 36 * 56;
+                hipLaunchKernelGGL(kern, dim3(cus * 2), dim3(256), 0, 0, out, 10, big);
+                hipEventRecord(e0);
+                for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(cus * 2), dim3(256), 0, 0, out, it, big);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                return 10.0 * 4096.0 * 64.0 * it * 4.0 * cus * 2 / ms * 1e-9;
+            };
+            printf(", \"32x32x1_2b\": {\"lds_only_swizzled\": %.1f", run(peak32_dlds<0>));
+            printf(", \"lds_only_padded_rows\": %.1f", run(peak32_dlds<4>));
+            printf(", \"+barrier\": %.1f", run(peak32_dlds<2>));
+            printf(", \"+direct_to_lds_loads\": %.1f", run(peak32_dlds<1>));
+            printf(", \"+both\": %.1f}", run(peak32_dlds<3>));
+        }
         printf(", \"mfma_only_read2\": %.1f", run_lds<16>(out, din, big, mask, cus, e0, e1));
         printf(", \"all_noperm_read2\": %.1f}", run_lds<16 + 7>(out, din, big, mask, cus, e0, e1));
     }
