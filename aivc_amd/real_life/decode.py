@@ -2,6 +2,7 @@
 (src/real_life/decode.py).  Decoder.decode keeps the reference's dictionary contract (float YUV
 dicts, one bitstream file per frame); decode_one_video reads the container and writes planar YUV
 directly (the reference's PNG triplets + per-frame `dd` forks are out of scope)."""
+import os
 import time
 
 import numpy as np
@@ -109,4 +110,47 @@ def decode_one_video(param):
     print_log_msg('RESULT', 'Decoding FPS', '[frame/s]', '%.1f' % (n / dt))
     if out_file:
         write_yuv(frames, out_file)
+    if get_value('flag_bitstream_debug', param, default):
+        check_debug_md5(frames, first, debug_dir(path))
     return frames
+
+
+def debug_dir(bitstream_path):
+    """where flag_bitstream_debug keeps the encoder's per-plane digests: '<bitstream>.debug/' (the reference uses
+    '<root>/debug/<sequence>/' next to its PNG folders, src/model_mngt/model_management.py:132-135)"""
+    return bitstream_path + '.debug'
+
+
+def plane_md5(plane):
+    import hashlib
+    a = plane.cpu().numpy() if isinstance(plane, torch.Tensor) else np.asarray(plane)
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def write_debug_md5(frames, first, directory):
+    """encoder side of flag_bitstream_debug: '<idx>_<c>.md5' per reconstructed plane.  The reference hashes the PNG
+    files it writes (src/real_life/decode.py:304-326); there are no PNGs here, the digest is of the 8-bit plane."""
+    os.makedirs(directory, exist_ok=True)
+    for i, fr in enumerate(frames):
+        for c in 'yuv':
+            with open(os.path.join(directory, '%d_%s.md5' % (first + i, c)), 'w') as f:
+                f.write(plane_md5(fr[c]))
+
+
+def check_debug_md5(frames, first, directory):
+    """decoder side: same messages as src/real_life/decode.py:318-326; -> number of mismatching planes"""
+    bad = 0
+    for i, fr in enumerate(frames):
+        for c in 'yuv':
+            name = '%d_%s' % (first + i, c)
+            with open(os.path.join(directory, name + '.md5')) as f:
+                encoder_md5 = f.read().strip()
+            msg = name + ': '
+            if encoder_md5 != plane_md5(fr[c]):
+                bad += 1
+                msg += '\n' + '-' * 80 + '\n' + 'Incorrect reconstruction!\n' + '-' * 80 + '\n'
+            else:
+                msg += 'Identical reconstruction!'
+            print(msg)
+        print('')
+    return bad

@@ -68,6 +68,9 @@ def encode(param):
         f.write(blob)
     n = last - first + 1
     recs = [r for g in enc['recs'] for r in g][:n]
+    if get_value('flag_bitstream_debug', param, default):
+        from .decode import debug_dir, write_debug_md5
+        write_debug_md5(recs, first, debug_dir(final_file))
     se = sum(float(((r[k].float() - f[k].float()) ** 2).sum()) for r, f in zip(recs, frames) for k in 'yuv')
     cnt = sum(f[k].numel() for f in frames for k in 'yuv')
     psnr = 10 * np.log10(255.0 ** 2 / max(se / cnt, 1e-12))

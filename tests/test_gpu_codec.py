@@ -349,3 +349,36 @@ def test_path_api_debug_flags(cuda, tmp_path, capsys):
     assert capsys.readouterr().out.count('All good for') == 2 and not ac.md5_errors
     raw = open(path, 'rb').read()
     assert raw[:8] == bytes(8)  # the two empty MOFNet sections of an I frame
+
+
+def test_bitstream_debug_flag(cuda, tmp_path, capsys):
+    """flag_bitstream_debug: the encoder leaves one digest per reconstructed plane next to the bitstream, the
+    decoder compares its own planes with them (closed loop check without a second file format)"""
+    from aivc_amd import synth
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    from aivc_amd.models import arch
+    from aivc_amd.real_life.decode import Decoder, debug_dir, decode_one_video
+    from aivc_amd.real_life.encode import encode
+    model = synth.make_model(arch.TINY_WIDTHS, seed=31, device=cuda)
+    w, h, n = 64, 48, 3
+    raw = tmp_path / ('clip_%dx%d_30_420.yuv' % (w, h))
+    with open(raw, 'wb') as f:
+        for fr in synth.synthetic_video(w, h, n):
+            for k in 'yuv':
+                f.write(fr[k].tobytes())
+    bits = str(tmp_path / 'b.bin')
+    encode({'model': model, 'sequence_path': str(raw), 'GOP_struct': generate_gop_struct('1_GOP_2'),
+            'GOP_struct_name': '1_GOP_2', 'final_file': bits, 'idx_starting_frame': 0, 'idx_end_frame': n - 1,
+            'flag_bitstream_debug': True})
+    assert len(os.listdir(debug_dir(bits))) == 3 * n
+    capsys.readouterr()
+    decode_one_video({'decoder': Decoder({'full_net': model, 'device': 'cuda:0'}), 'bitstream_path': bits, 'device': 'cuda:0',
+                      'flag_bitstream_debug': True})
+    out = capsys.readouterr().out
+    assert out.count('Identical reconstruction!') == 3 * n and 'Incorrect' not in out
+    with open(os.path.join(debug_dir(bits), '1_u.md5'), 'w') as f:
+        f.write('0' * 32)
+    decode_one_video({'decoder': Decoder({'full_net': model, 'device': 'cuda:0'}), 'bitstream_path': bits, 'device': 'cuda:0',
+                      'flag_bitstream_debug': True})
+    out = capsys.readouterr().out
+    assert out.count('Incorrect reconstruction!') == 1 and out.count('Identical reconstruction!') == 3 * n - 1
