@@ -33,34 +33,33 @@ def msssim(image0, image1):
 
 
 def evaluate(submission_images, target_images, settings={}, logger=None):
-    """metrics.py:6-56 with planes instead of PNG paths -> {'PSNR', 'MSSSIM', 'MSSSIM_dB'}"""
-    if settings is None:
-        settings = {}
+    """metrics.py:6-56 with planes instead of PNG paths -> {'PSNR', 'MSSSIM', 'MSSSIM_dB'}.
+    Squared errors and MS-SSIM scores are pooled over all planes weighted by their sample counts."""
     if isinstance(settings, str):
         try:
             settings = json.loads(settings)
         except json.JSONDecodeError:
             settings = {}
-    metrics = settings.get('metrics', ['PSNR', 'MSSSIM'])
-    num_dims = 0
-    sqerror_values, msssim_values = [], []
-    for name in target_images:
-        image0, image1 = target_images[name], submission_images[name]
-        size = int(np.prod(tuple(image0.shape)))
-        num_dims += size
-        if 'PSNR' in metrics:
-            sqerror_values.append(mse(image1, image0))
-        if 'MSSSIM' in metrics:
-            value = msssim(image0, image1) * size
-            if np.isnan(value):
-                value = 0.0
+    wanted = (settings or {}).get('metrics', ['PSNR', 'MSSSIM'])
+    want_psnr, want_ms = 'PSNR' in wanted, 'MSSSIM' in wanted
+    samples, sq_total, ms_total = 0, 0.0, 0.0
+    for name, ref_plane in target_images.items():
+        got_plane = submission_images[name]
+        count = int(np.prod(tuple(ref_plane.shape)))
+        samples += count
+        if want_psnr:
+            sq_total += mse(got_plane, ref_plane)
+        if want_ms:
+            score = msssim(ref_plane, got_plane)
+            if np.isnan(score):  # a negative contrast term at a coarse scale; the reference counts it as zero
+                score = 0.0
                 if logger:
                     logger.warning('Evaluation of MSSSIM for `%s` returned NaN. Assuming MSSSIM is zero.' % name)
-            msssim_values.append(value)
+            ms_total += score * count
     results = {}
-    if 'PSNR' in metrics:
-        results['PSNR'] = mse2psnr(np.sum(sqerror_values) / num_dims)
-    if 'MSSSIM' in metrics:
-        results['MSSSIM'] = np.sum(msssim_values) / num_dims
-        results['MSSSIM_dB'] = -10 * np.log10(1 - results.get('MSSSIM'))
+    if want_psnr:
+        results['PSNR'] = mse2psnr(sq_total / samples)
+    if want_ms:
+        results['MSSSIM'] = ms_total / samples
+        results['MSSSIM_dB'] = -10 * np.log10(1 - results['MSSSIM'])
     return results
