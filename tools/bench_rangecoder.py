@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Tuning aid: per-symbol cost of range_encode_kernel / range_decode_kernel on Laplace-coded latents.
+usage: bench_rangecoder.py   (env NSTREAMS, MAPS, SCALE)"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from aivc_amd import ops
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        r = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, r
+
+
+def main():
+    dev = torch.device('cuda:0')
+    h, w, c = 68, 120, 64
+    g = torch.Generator(device=dev).manual_seed(1)
+    for nstreams in (1, 8, 64):
+        for n_maps in (12, 64):
+            for sig in (0.3, 1.5, 6.0, 30.0):
+                maps = list(range(n_maps))
+                sigma = (torch.rand((1, h, w, c), generator=g, device=dev) * 0.5 + 0.75) * sig
+                q = (torch.randn((1, h, w, c), generator=g, device=dev) * sigma * 0.7).round().clamp(-256, 255).to(torch.int16)
+                bounds = [ops.laplace_bounds(sigma, q, maps) for _ in range(nstreams)]
+                nsym = n_maps * h * w
+                ms_e, (out, lens, offs) = timed(lambda: ops.range_encode(bounds))
+                lens_h = lens.cpu().numpy()
+                out_h = out.cpu().numpy()
+                payloads = [out_h[o:o + int(l)].tobytes() for (o, _), l in zip(offs, lens_h)]
+                rows = torch.empty((nstreams * nsym, 520), dtype=torch.int16, device=dev)
+                for i in range(nstreams):
+                    ops.laplace_cdf_rows(sigma, maps, out=rows, row_off=i * nsym)
+                ms_d, dec = timed(lambda: ops.range_decode(payloads, rows, [i * nsym for i in range(nstreams)], [nsym] * nstreams, [0] * nstreams))
+                sym = (q[0].reshape(-1, c)[:, :n_maps].t().reshape(-1).to(torch.int32) + 256).to(torch.int16)
+                ok = all(torch.equal(d, sym) for d in dec)
+                print('streams %2d maps %2d sigma %5.1f: %6d sym/stream  %5.2f bit/sym  encode %6.2f ms (%.3f us/sym)  decode %6.2f ms (%.3f us/sym)  %s'
+                      % (nstreams, n_maps, sig, nsym, 8.0 * lens_h.mean() / nsym, ms_e, ms_e * 1e3 / nsym, ms_d, ms_d * 1e3 / nsym, 'ok' if ok else 'MISMATCH'))
+
+
+if __name__ == '__main__':
+    main()
