@@ -204,10 +204,19 @@ class FrameCodec:
         fbytes = [dict() for _ in units]
         data_dim = None
         sides = self._side_streams(self.entropy_streams)
-        side, forks = sides[0], sides[1:]
         jobs = []
         waiting = None  # (items, sections, flags on their way to the host) of the previous level
-        for level in coding_levels(gop):
+
+        def flush(li):
+            # the levels' coder launches are independent of each other: rotate the stream so that a level with
+            # long streams (few frames, big latents) does not queue the following ones behind it
+            k = li % len(sides)
+            jobs.append((waiting[0], launch_finalize(waiting[1], sides[k], prepared=waiting[2],
+                                                     fork_streams=sides[k + 1:] + sides[:k])))
+
+        n_levels = 0
+        for li, level in enumerate(coding_levels(gop)):
+            n_levels = li + 1
             pending = []
             for ftype, chunk in self._chunks(gop, level, range(len(units))):
                 out = self.encode_batch([units[u][frame_index(f)] for u, f in chunk],
@@ -217,17 +226,17 @@ class FrameCodec:
                 for (u, f), r in zip(chunk, out['rec']):
                     rec[u][f] = r
                 pending.append((chunk, out['sections']))
-            # entropy coding runs on the side stream one level behind the transforms: the flags of THIS level
+            # entropy coding runs on the side streams one level behind the transforms: the flags of THIS level
             # start their trip to the host now, the host picks them up (and launches the range coder) only
             # after the next level's transforms are queued, so the main stream never drains on that wait
             all_secs = [s for _, secs in pending for s in secs]
             items = [it for chunk, _ in pending for it in chunk]
             prep = prepare_finalize(all_secs)
             if waiting is not None:
-                jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2], fork_streams=forks)))
+                flush(li - 1)
             waiting = (items, all_secs, prep)
         if waiting is not None:
-            jobs.append((waiting[0], launch_finalize(waiting[1], side, prepared=waiting[2], fork_streams=forks)))
+            flush(n_levels - 1)
         for items, job in jobs:
             for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b

@@ -122,6 +122,8 @@ def main():
     ap.add_argument('--gop', type=str, default='1_GOP_32')
     ap.add_argument('--units', type=int, default=4, help='intra-period units per step per GPU (4 x 33 = the 128-frame clip of BASELINE configs[3])')
     ap.add_argument('--max-batch', type=int, default=8)
+    ap.add_argument('--entropy-streams', type=int, default=4, help='decoder: concurrent range-coder chains')
+    ap.add_argument('--entropy-lookahead', type=int, default=2, help='decoder: dependency levels of entropy decoding issued ahead')
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -150,7 +152,8 @@ def main():
     if use_dist:
         broadcast_model(model)  # the one collective: weights over RCCL/xGMI
     from aivc_amd.codec import FrameCodec
-    fc = FrameCodec(model, max_batch=args.max_batch)
+    fc = FrameCodec(model, max_batch=args.max_batch, entropy_streams=args.entropy_streams,
+                    entropy_lookahead=args.entropy_lookahead)
     unit = len(generate_gop_struct(args.gop))
     per_step = unit * args.units
     n_total = args.warmup + args.steps + 1
