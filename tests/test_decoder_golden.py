@@ -1,0 +1,266 @@
+"""Decoder dataflow, section framing and the md5 debug format pinned against fixtures produced by RUNNING the
+reference's own code (tools/gen_golden_decoder.py): ArithmeticCoder.encode wrote every section
+(src/real_life/bitstream.py:186-304), cat_one_gop / cat_one_video wrapped them, decode_one_video ->
+decode_one_GOP -> Decoder.decode (src/real_life/decode.py:44-898) produced the PNG planes.  The only part not
+from the reference is the torchac arithmetic (oracle coder behind a stub: "parity unpinned") and the
+motion-compensation one-liner of the missing models package.
+
+CPU half: the oracle against the fixtures.  GPU half (-m gpu): the HIP product path against the same fixtures,
+with no oracle in between."""
+import ast
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import codec as ocodec
+from oracle import spec as ospec
+
+CASES = ['decoder_ra', 'decoder_ra_chained', 'decoder_ldp_odd']
+NAMES = ('mofnet', 'codecnet')
+
+
+def _meta(g):
+    return ast.literal_eval(str(g['meta']))
+
+
+def _model(golden, device=None):
+    """this repo's FullNet carrying the reference model's weights (strict state_dict load: the names match)"""
+    from aivc_amd.model_mngt.model_management import attach_arithmetic_coders
+    from aivc_amd.models.full_net import FullNet
+    g = golden('decoder_model')
+    m = _meta(g)
+    model = FullNet({'widths': m['widths'], 'nb_rates': m['nb_rates']})
+    sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model = model.eval()
+    if device is not None:
+        model = attach_arithmetic_coders(model.to(device))
+    return model
+
+
+def _frames(g, m, prefix):
+    return [{k: np.asarray(g['%s_%d_%s' % (prefix, m['first'] + i, k)]) for k in 'yuv'} for i in range(m['n'])]
+
+
+def _sections_from_latents(g, idx, net_spec, name, md5=False):
+    """restated framing of one conditional coder's two sections from the reference's own latents"""
+    from oracle import oracle as O
+    z = np.asarray(g['lat_%d_%s_z' % (idx, name)])
+    q = np.asarray(g['lat_%d_%s_q' % (idx, name)])
+    sigma = np.asarray(g['lat_%d_%s_sigma' % (idx, name)])
+    nhwc = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+    table, _ = O.balle_cdf_table(net_spec['balle'])
+    sz = ocodec._z_section(table, nhwc(z).astype(np.int16))
+    sy = ocodec._y_section(nhwc(sigma), nhwc(q).astype(np.int16))
+    if md5:
+        sz = _savetxt_md5(z) + sz
+        sy = _savetxt_md5(q) + sy
+    return sz, sy
+
+
+def _savetxt_md5(x_nchw):
+    """what the reference computes under flag_md5sum (bitstream.py:229-234): md5 of np.savetxt of the latent"""
+    import io
+    buf = io.BytesIO()
+    np.savetxt(buf, x_nchw.astype(np.int16).astype(int).flatten())
+    return hashlib.md5(buf.getvalue()).hexdigest().encode()
+
+
+# ---- CPU: oracle vs reference -----------------------------------------------------------------------------
+@pytest.mark.parametrize('case', CASES)
+def test_reference_said_lossless(case, golden):
+    g = golden(case)
+    m = _meta(g)
+    gop = ocodec.gop_struct(m['gop'])
+    n_sections = sum(2 if gop[i % len(gop)][0] == 0 else 4 for i in range(m['n']))
+    # every section was written twice (plain + md5 variant), each decode-back said "lossless"
+    assert int(g['ref_log_counts'][0]) == 2 * n_sections and int(g['ref_log_counts'][1]) == n_sections
+    assert int(g['cdf_stats'][3]) == 0  # same sigma: both CDF arithmetics agree on every coded bound
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_container_holds_reference_frames(case, golden):
+    g = golden(case)
+    m = _meta(g)
+    blob = np.asarray(g['video_file']).tobytes()
+    v = [int.from_bytes(blob[i:i + 2], 'big') for i in range(0, 18, 2)]
+    dd = m['data_dim']
+    assert tuple(v[:6]) == dd['x'] + dd['y'] + dd['z'] and v[7] == m['first'] and v[8] == m['first'] + m['n'] - 1
+    unit = len(ocodec.gop_struct(m['gop']))
+    idx = m['first']
+    for gb in ocodec.split_lp(blob, 18, v[6]):
+        assert gb[:6] == ocodec.gop_header(m['gop'], m['idx_rate'])
+        for fb in ocodec.split_lp(gb, 6, unit):
+            assert fb == np.asarray(g['frame_%d' % idx]).tobytes()
+            idx += 1
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_framing_equals_reference_encode(case, oracle, golden):
+    """sections restated from the reference's latents == bytes its ArithmeticCoder.encode wrote, plain and md5"""
+    g = golden(case)
+    m = _meta(g)
+    spec = ospec.export_model(_model(golden))
+    gop = ocodec.gop_struct(m['gop'])
+    for i in range(m['n']):
+        idx = m['first'] + i
+        ftype = gop[i % len(gop)][0]
+        for md5, key in ((False, 'frame_%d'), (True, 'md5frame_%d')):
+            secs = [None, None]
+            if ftype != ocodec.FRAME_I:
+                secs = list(_sections_from_latents(g, idx, spec['mof'], 'mofnet', md5))
+            secs += list(_sections_from_latents(g, idx, spec['cod'], 'codecnet', md5))
+            frame = b''.join(ocodec.be(0, 4) if s is None else ocodec.lp(s) for s in secs)
+            assert frame == np.asarray(g[key % idx]).tobytes(), (case, idx, md5)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_decode_equals_reference_decoder(case, oracle, golden):
+    g = golden(case)
+    m = _meta(g)
+    spec = ospec.export_model(_model(golden))
+    dec = ocodec.decode_video(spec, np.asarray(g['video_file']).tobytes())
+    want = _frames(g, m, 'dec')
+    assert len(dec) == m['n']
+    n_off = 0
+    for d, w in zip(dec, want):
+        for k in 'yuv':
+            diff = np.abs(d[k].astype(np.int32) - w[k].astype(np.int32))
+            assert diff.max() <= 1, (case, k)  # north_star: within 1 LSB of the reference
+            n_off += int((diff != 0).sum())
+    assert n_off <= 4  # rounding ties only (0 on the fixtures as generated)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_latents_equal_reference(case, oracle, golden):
+    """entropy stage alone: z, then q_y through the oracle's own h_s / sigma / CDF rows"""
+    from oracle import oracle as O
+    g = golden(case)
+    m = _meta(g)
+    spec = ospec.export_model(_model(golden))
+    gop = ocodec.gop_struct(m['gop'])
+    dy, dz = m['data_dim']['y'], m['data_dim']['z']
+    for i in range(m['n']):
+        idx = m['first'] + i
+        sec = ocodec.split_lp(np.asarray(g['frame_%d' % idx]).tobytes(), 0, 4)
+        for k, name in enumerate(NAMES):
+            if name == 'mofnet' and gop[i % len(gop)][0] == ocodec.FRAME_I:
+                assert sec[0] == b'' and sec[1] == b''
+                continue
+            net = spec['mof' if name == 'mofnet' else 'cod']
+            table, _ = O.balle_cdf_table(net['balle'])
+            npz, npy = dz[0] * dz[1], dy[0] * dy[1]
+            sym = O.range_decode(sec[2 * k], table, net['c_z'] * npz, plane=npz)
+            q_z = O.scatter_symbols(sym, npz, net['c_z'], list(range(net['c_z']))).reshape(1, dz[0], dz[1], -1)
+            np.testing.assert_array_equal(np.transpose(q_z, (0, 3, 1, 2)), g['lat_%d_%s_z' % (idx, name)])
+            mu, sigma = O.hyper_params(O.run_layer(net['h_s'], O.dequantize(q_z)), net['c_y'], dy[0], dy[1])
+            np.testing.assert_allclose(np.transpose(sigma, (0, 3, 1, 2)), g['lat_%d_%s_sigma' % (idx, name)], rtol=2e-5)
+            sy = sec[2 * k + 1]
+            maps = list(sy[1:1 + sy[0]])
+            q_y = np.zeros((npy, net['c_y']), np.int16)
+            if maps:
+                sym = O.range_decode(sy[1 + sy[0]:], O.laplace_cdf_rows(sigma, maps), len(maps) * npy)
+                q_y = O.scatter_symbols(sym, npy, net['c_y'], maps)
+            np.testing.assert_array_equal(np.transpose(q_y.reshape(1, dy[0], dy[1], -1), (0, 3, 1, 2)),
+                                          g['lat_%d_%s_q' % (idx, name)])
+
+
+def test_md5_text_format(golden):
+    """the product's latent_md5 == the 32 bytes the reference's compute_md5sum put in front of the sections"""
+    from aivc_amd.real_life.bitstream import latent_md5
+    g = golden('decoder_ra')
+    m = _meta(g)
+    for i in range(m['n']):
+        idx = m['first'] + i
+        sec = ocodec.split_lp(np.asarray(g['md5frame_%d' % idx]).tobytes(), 0, 4)
+        for k, name in enumerate(NAMES):
+            if not sec[2 * k]:
+                continue
+            for s, lat in ((sec[2 * k], 'z'), (sec[2 * k + 1], 'q')):
+                x = torch.from_numpy(np.asarray(g['lat_%d_%s_%s' % (idx, name, lat)]))
+                assert latent_md5(x.permute(0, 2, 3, 1).to(torch.int16)) == s[:32]
+
+
+# ---- GPU: HIP product path vs reference (no oracle involved) --------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES)
+def test_hip_decode_video_equals_reference_decoder(case, cuda, golden):
+    g = golden(case)
+    m = _meta(g)
+    model = _model(golden, cuda)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        dec, data_dim, first, last = fc.decode_video(np.asarray(g['video_file']).tobytes(), cuda)
+    assert (first, last) == (m['first'], m['first'] + m['n'] - 1)
+    assert {k: tuple(v) for k, v in data_dim.items()} == m['data_dim']
+    n_off = 0
+    for d, w in zip(dec, _frames(g, m, 'dec')):
+        for k in 'yuv':
+            diff = np.abs(d[k][0].cpu().numpy().astype(np.int32) - w[k].astype(np.int32))
+            assert diff.max() <= 1, (case, k)
+            n_off += int((diff != 0).sum())
+    assert n_off <= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES)
+def test_hip_frame_decoder_per_frame(case, cuda, golden):
+    """Decoder.decode one frame at a time with the REFERENCE's reconstructions as references (no drift)"""
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    g = golden(case)
+    m = _meta(g)
+    model = _model(golden, cuda)
+    fc = model.frame_codec()
+    gop = generate_gop_struct(m['gop'])
+    want = _frames(g, m, 'dec')
+    dd = dict(m['data_dim'])
+    dev = lambda p: None if p is None else {k: torch.from_numpy(p[k])[None].to(cuda) for k in 'yuv'}
+    for i in range(m['n']):
+        u0 = i - i % len(gop)
+        d = gop['frame_%d' % (i % len(gop))]
+        ref = lambda nm: None if nm is None else want[u0 + int(nm.split('_')[-1])]
+        with torch.no_grad():
+            out = fc.decode_frame(np.asarray(g['frame_%d' % (m['first'] + i)]).tobytes(), dev(ref(d['prev_ref'])),
+                                  dev(ref(d['next_ref'])), d['type'], dd, m['idx_rate'], cuda)
+        for k in 'yuv':
+            diff = np.abs(out[k][0].cpu().numpy().astype(np.int32) - want[i][k].astype(np.int32))
+            assert diff.max() <= 1, (case, i, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('md5', [False, True])
+@pytest.mark.parametrize('case', CASES)
+def test_hip_arithmetic_coder_path_api(case, md5, cuda, golden, tmp_path, capsys):
+    """ArithmeticCoder.encode / .decode with the reference's signatures: the files this repo writes from the
+    reference's latents are byte-identical to the ones the reference wrote, and decode back to them."""
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    g = golden(case)
+    m = _meta(g)
+    model = _model(golden, cuda)
+    gop = generate_gop_struct(m['gop'])
+    nets = {'mofnet': model.mode_net.mode_net, 'codecnet': model.codec_net.codec_net}
+    for i in range(m['n']):
+        idx = m['first'] + i
+        path = str(tmp_path / str(idx))
+        lat = lambda name, what: torch.from_numpy(np.asarray(g['lat_%d_%s_%s' % (idx, name, what)])).to(cuda)
+        names = NAMES if gop['frame_%d' % (i % len(gop))]['type'] != 0 else NAMES[1:]
+        for name in names:
+            common = {'bitstream_path': path, 'flag_debug': True, 'flag_md5sum': md5}
+            nets[name].ac.encode(dict(common, x=lat(name, 'z'), mode='pmf', latent_name=name + '_z'))
+            nets[name].ac.encode(dict(common, x=lat(name, 'q'), mode='laplace', sigma=lat(name, 'sigma'),
+                                      latent_name=name + '_y'))
+        with open(path, 'rb') as f:
+            assert f.read() == np.asarray(g[('md5frame_%d' if md5 else 'frame_%d') % idx]).tobytes(), (case, idx)
+        for name in names:
+            z = nets[name].ac.decode({'mode': 'pmf', 'bitstream_path': path, 'data_dim': tuple(lat(name, 'z').shape),
+                                      'device': cuda, 'latent_name': name + '_z', 'flag_md5sum': md5})
+            assert torch.equal(z, lat(name, 'z'))
+            q = nets[name].ac.decode({'mode': 'laplace', 'bitstream_path': path, 'sigma': lat(name, 'sigma'),
+                                      'data_dim': tuple(lat(name, 'q').shape), 'device': cuda,
+                                      'latent_name': name + '_y', 'flag_md5sum': md5})
+            assert torch.equal(q, lat(name, 'q'))
+    out = capsys.readouterr().out
+    assert 'Ko!' not in out and '[Error]' not in out and 'Ok! Entropy coding is lossless' in out

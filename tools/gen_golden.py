@@ -72,6 +72,10 @@ def save(name, **arrs):
 
 
 def main():
+    global OUT
+    if len(sys.argv) > 2 and sys.argv[1] == '--out':
+        OUT = sys.argv[2]
+    torch.manual_seed(666)  # BallePdfEstim / GainMatrix draw their initial parameters from the global generator
     install_stubs()
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
