@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void laplace_bounds_kernel(const float *__rest
   const int ch = maps.idx[pos / npix];
   const size_t pix = pos % npix;
   const float s = sigma[pix * c + ch];
-  const int sym = (int)q[pix * c + ch] + AIVC_AC_MAX_VAL;
+  // symbols outside the alphabet [0, 511] never reach this kernel through the codec (quantize_center clamps,
+  // the path API raises like torchac's check_input_bounds); the clamp keeps a misuse memory-safe
+  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), 2 * AIVC_AC_MAX_VAL - 1);
   const uint32_t lo = aivc_laplace_cdf_u16(sym, s), hi = aivc_laplace_cdf_u16(sym + 1, s);
   bounds[pos] = lo | (hi << 16);
 }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void table_bounds_kernel(const uint16_t *__res
   if (pos >= (size_t)c * npix) return;
   const int ch = (int)(pos / npix);
   const size_t pix = pos % npix;
-  const int sym = (int)q[pix * c + ch] + AIVC_AC_MAX_VAL;
+  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), 2 * AIVC_AC_MAX_VAL - 1);
   const uint16_t *row = table + (size_t)ch * AIVC_CDF_ROW;
   bounds[pos] = (uint32_t)row[sym] | ((uint32_t)row[sym + 1] << 16);
 }

@@ -24,6 +24,10 @@ def broadcast_model(model, src=0):
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src)
+    # writing through .data does not bump Parameter._version, which is what the packed-weight / GDN / z-table
+    # cache is stamped with: anything cached before the broadcast would stay stale on the receiving ranks
+    from .layers import _cache
+    _cache.clear()
     return model
 
 

@@ -48,7 +48,13 @@ def _worker(rank, world, port, q):
     from aivc_amd.models import arch
     from oracle import spec as ospec
     model = synth.make_model(arch.TINY_WIDTHS, seed=100 + rank)  # different weights per rank ...
+    # something cached from the pre-broadcast weights (bench.py calibrates on the GPU before the broadcast)
+    from aivc_amd.layers import _cache
+    conv = model.codec_net.codec_net.g_a[0].layers[1]
+    _cache.cached(conv, 'probe', (conv.weight,), lambda: conv.weight.detach().clone())
     parallel.broadcast_model(model)                            # ... until the broadcast
+    probe = _cache.cached(conv, 'probe', (conv.weight,), lambda: conv.weight.detach().clone())
+    assert torch.equal(probe, conv.weight), 'packed-parameter cache survived broadcast_model (stale weights)'
     frames = synth.synthetic_video(48, 32, 7, seed=2)
     codec = OracleUnitCodec(ospec.export_model(model))
     blob = parallel.encode_video_sharded(codec, frames, 'LDP_2')
