@@ -1,6 +1,6 @@
 // conv_direct.hip -- scalar (one thread per output value) implementation of the conv family.
 // It is the always-available path: every shape the ABI accepts runs here, with exactly the
-// fmaf-chain arithmetic of include/aivc_hip.h.  The MFMA kernels (conv_mfma.hip) must agree with
+// fmaf-chain arithmetic (AIVC_K_ORDER) of include/aivc_hip.h.  The MFMA kernels (conv_mfma.hip) must agree with
 // it bit for bit; thin layers (c_out of 3 or 6) stay on this path.
 #include "common.h"
 
@@ -21,37 +21,40 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(aivc_conv_params p) {
   const float *wrow = p.w + (size_t)co * k * k * Ci;
   const float *xn = p.x + (size_t)n * H * W * Ci;
   float acc = 0.0f;
+  // reduction index kk = t * Ci + ci over the tap list of this output (all k*k taps; transposed conv: the taps
+  // of the pixel's parity class), walked in groups of 8 in AIVC_K_ORDER -- the arithmetic contract of
+  // include/aivc_hip.h.  Out-of-image taps of the transposed conv are exact no-ops and skipped.
+  int ky0 = 0, kx0 = 0, nkx = k, ntap = k * k, tstep = 1, tpad = 0;
   if (MODE == AIVC_MODE_TCONV) {
-    const int tpad = (k + 1) / 2 - 1;
-    for (int ky = 0; ky < k; ++ky) {
-      const int ty = oy + tpad - ky;
-      if (ty < 0 || (ty & 1) || (ty >> 1) >= H) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int tx = ox + tpad - kx;
-        if (tx < 0 || (tx & 1) || (tx >> 1) >= W) continue;
-        const float *xp = xn + ((size_t)(ty >> 1) * W + (tx >> 1)) * Ci;
-        const float *wp = wrow + (size_t)(ky * k + kx) * Ci;
-        for (int ci = 0; ci < Ci; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci], acc);
-      }
-    }
-  } else {
-    for (int ky = 0; ky < k; ++ky) {
-      int iy = oy * p.stride + ky - p.pad;
-      iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
-      for (int kx = 0; kx < k; ++kx) {
-        int ix = ox * p.stride + kx - p.pad;
+    tpad = (k + 1) / 2 - 1;
+    ky0 = (oy + tpad) & 1;
+    kx0 = (ox + tpad) & 1;
+    nkx = (k - kx0 + 1) / 2;
+    ntap = ((k - ky0 + 1) / 2) * nkx;
+    tstep = 2;
+  }
+  const int K = ntap * Ci;
+  for (int g = 0; g < K; g += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kk = g + AIVC_K_ORDER(i);
+      if (kk >= K) continue;
+      const int t = kk / Ci, ci = kk - t * Ci;
+      const int ky = ky0 + tstep * (t / nkx), kx = kx0 + tstep * (t % nkx);
+      int iy, ix;
+      if (MODE == AIVC_MODE_TCONV) {
+        iy = (oy + tpad - ky) >> 1;  // even by construction of the class
+        ix = (ox + tpad - kx) >> 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      } else {
+        iy = oy * p.stride + ky - p.pad;
+        ix = ox * p.stride + kx - p.pad;
+        iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
         ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
-        const float *xp = xn + ((size_t)iy * W + ix) * Ci;
-        const float *wp = wrow + (size_t)(ky * k + kx) * Ci;
-        if (MODE == AIVC_MODE_GDN || MODE == AIVC_MODE_IGDN) {
-          for (int ci = 0; ci < Ci; ++ci) {
-            const float a = xp[ci];
-            acc = __builtin_fmaf(a * a, wp[ci], acc);
-          }
-        } else {
-          for (int ci = 0; ci < Ci; ++ci) acc = __builtin_fmaf(xp[ci], wp[ci], acc);
-        }
       }
+      float a = xn[((size_t)iy * W + ix) * Ci + ci];
+      if (MODE == AIVC_MODE_GDN || MODE == AIVC_MODE_IGDN) a = a * a;
+      acc = __builtin_fmaf(a, wrow[(size_t)(ky * k + kx) * Ci + ci], acc);
     }
   }
   Epilogue ep{p.bias, p.mul, p.res, p.x, p.y, p.act1, p.act2, MODE};

@@ -1,24 +1,32 @@
 // conv_mfma.hip -- implicit-GEMM convolution family on the gfx950 matrix cores, exact fp32.
 //
 //   GEMM view      M = output pixels (n, oy, ox), N = output channels, K = (ky, kx, ci)
-//   instruction    v_mfma_f32_32x32x2_f32: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), a k-ordered fp32
-//                  fmaf chain, so chaining MFMAs along ascending K reproduces bit for bit the scalar
-//                  kernels / CPU oracle (no split-K, no atomics, one accumulator per output).
+//   instruction    v_mfma_f32_32x32x2_f32: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) with k0 supplied by lanes 0-31
+//                  and k1 by lanes 32-63: a fixed-order fp32 fmaf chain (no split-K, no atomics, one accumulator
+//                  per output).
+//   accumulation   THE ARITHMETIC CONTRACT of the conv family (include/aivc_hip.h): the reduction index
+//   order          kk = tap * c_in + ci (taps in (ky, kx) order; transposed conv: the taps of the output's parity
+//                  class) is walked in groups of 8, inside a group in the order 0, 4, 1, 5, 2, 6, 3, 7.  That is
+//                  what the MFMA does when an LDS row holds K in natural order and lane half h reads the 16 bytes
+//                  at column 8 o + 4 h: step s multiplies k = 8 o + s (half 0) then k = 8 o + 4 + s (half 1).
+//                  Staging is therefore a plain copy global -> registers -> LDS (a permuted LDS layout that
+//                  reproduced an ascending chain cost 32 v_mov per K-tile and thread; measured: every issued
+//                  instruction costs the fp32 matrix pipe ~4.4 cycles).  The scalar kernel, the thin kernels and
+//                  the CPU oracle walk K in the same order, so all of them agree bit for bit.
 //   roofline       fp32 MFMA = 157.3 TFLOP/s dense (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz).
 //   data layout    activations NHWC, weights OHWI: a K-slice of one pixel / one output channel is a
 //                  contiguous run of floats -> every global access is a 16-byte load.
 //   staging        global -> registers (issued one K-tile ahead, in flight during the MFMAs) ->
 //                  LDS (one buffer, 2 barriers per K-tile; 2-3 workgroups per CU hide them).
-//                  LDS rows hold BK = 32 K-values (+4 pad -> conflict-free ds_read_b128).  Inside
-//                  each group of 8 consecutive K the even ks are stored first, then the odd ks:
-//                  lane half h = lane>>5 of the MFMA needs k = 2j + h, so one ds_read_b128 at
-//                  column 8*o + 4*h yields its operand for 4 consecutive MFMA steps.
+//                  LDS rows hold BK = 32 K-values (+4 pad -> conflict-free ds_read_b128).
 //   im2col         done in the loader's address arithmetic: replicate padding = clamp of the input
 //                  coordinate; transposed conv = 4 output-parity classes (slowest tile index), each a small
 //                  dense conv over the taps of that parity with zero fill outside the image.
 //   epilogue       bias / GDN division / activation / gate / residual fused, straight from the
 //                  accumulators (lanes 0-31 of a row write 128 contiguous bytes).
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -50,6 +58,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
   constexpr int UB = (BN * OCT + 255) / 256;  // ... for B
+  constexpr bool B_FULL = (BN * OCT) % 256 == 0;  // every thread stages a B unit: no exec masking
   constexpr bool TCONV = MODE == AIVC_MODE_TCONV;
   constexpr bool GDN = MODE == AIVC_MODE_GDN;  // covers IGDN (runtime mode in the epilogue)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   for (int j = 0; j < UB; ++j) {
     const int u = tid + 256 * j;
     const int co = n0 + u / OCT;
-    b_ok[j] = u < BN * OCT;
+    b_ok[j] = B_FULL || u < BN * OCT;
     const int coc = co < Cout ? co : Cout - 1;  // clamped: rows beyond c_out are never stored
     b_off[j] = TCONV ? (uint32_t)coc * (uint32_t)(ks * ks * Cin) + (uint32_t)((u % OCT) * 8)
                      : (uint32_t)coc * (uint32_t)K + (uint32_t)((u % OCT) * 8);
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     const uint32_t wk = TCONV ? (uint32_t)(((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0) : (uint32_t)kbase;
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      if (b_ok[j]) {
+      if (B_FULL || b_ok[j]) {
         const float *src = p.w + (b_off[j] + wk);
         rb[j][0] = *reinterpret_cast<const float4 *>(src);
         rb[j][1] = *reinterpret_cast<const float4 *>(src + 4);
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
           off = (uint32_t)coc * (uint32_t)K + (uint32_t)kc;
         }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b_ok[j]) v = *reinterpret_cast<const float4 *>(p.w + off);
+        if (B_FULL || b_ok[j]) v = *reinterpret_cast<const float4 *>(p.w + off);
         rb[j][q] = (kk < K && co < Cout) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -246,23 +255,23 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     else load_tile_generic(kt);
   };
 
-  auto store_tile_a = [&]() {
+  auto store_tile_a = [&](int buf_off = 0) {
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
       const int u = tid + 256 * j;
-      float *dst = As + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
-      *reinterpret_cast<float4 *>(dst) = make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z);
-      *reinterpret_cast<float4 *>(dst + 4) = make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w);
+      float *dst = As + buf_off + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
+      *reinterpret_cast<float4 *>(dst) = make_float4(ra[j][0].x, ra[j][0].y, ra[j][0].z, ra[j][0].w);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(ra[j][1].x, ra[j][1].y, ra[j][1].z, ra[j][1].w);
     }
   };
-  auto store_tile_b = [&]() {
+  auto store_tile_b = [&](int buf_off = 0) {
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const int u = tid + 256 * j;
-      if (u < BN * OCT) {
-        float *dst = Bs + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
-        *reinterpret_cast<float4 *>(dst) = make_float4(rb[j][0].x, rb[j][0].z, rb[j][1].x, rb[j][1].z);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(rb[j][0].y, rb[j][0].w, rb[j][1].y, rb[j][1].w);
+      if (B_FULL || u < BN * OCT) {
+        float *dst = Bs + buf_off + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(rb[j][0].x, rb[j][0].y, rb[j][0].z, rb[j][0].w);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(rb[j][1].x, rb[j][1].y, rb[j][1].z, rb[j][1].w);
       }
     }
   };
@@ -280,14 +289,14 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 
   // one K-tile of MFMAs out of LDS (measured in isolation, tools/mfma_probe.hip: this loop keeps the
   // matrix pipe 98% busy, i.e. what is lost in the whole kernel is lost outside of it)
-  auto mma_tile = [&](floatx16 (&c)[TM][TN]) {
+  auto mma_octs = [&](floatx16 (&c)[TM][TN], int buf_off, int o_lo, int o_hi) {
 #pragma unroll
-    for (int o = 0; o < OCT; ++o) {
+    for (int o = o_lo; o < o_hi; ++o) {
       float4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + buf_off + i * 32 * LDS_STRIDE + o * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + j * 32 * LDS_STRIDE + o * 8);
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + buf_off + j * 32 * LDS_STRIDE + o * 8);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       }
     }
   };
+  auto mma_tile = [&](floatx16 (&c)[TM][TN]) { mma_octs(c, 0, 0, OCT); };
 
   load_tile(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     if (kt + 1 < nkt) load_tile(kt + 1);
     mma_tile(acc);
   }
+
 
   // ---- fused (I)GDN: second, small GEMM  s[m][i] = sum_j x[m][j]^2 * gamma[i][j]  -------------
   // The biased conv outputs x stay in `acc`; their squares go through LDS (the A tile buffer) one
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
         }
     }
     const int k_in = lane & 31;
-    const int pos = (k_in >> 3) * 8 + (k_in & 1) * 4 + ((k_in & 7) >> 1);  // even ks first inside an octet
+    const int pos = k_in;  // natural channel order in the LDS row (see the accumulation order in the header)
     constexpr int NB = BK / 32;  // 32-channel accumulator blocks per K chunk
     const int nk2 = Cout / BK;
     for (int kt2 = 0; kt2 < nk2; ++kt2) {
@@ -361,7 +372,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              const float xv = acc[i][j][r];
+              float xv = acc[i][j][r];
+              asm volatile("" : "+v"(xv));  // keeps the squares inside the loop (hoisted, they cost 64 registers)
               As[row * LDS_STRIDE + blk * 32 + pos] = xv * xv;
             }
         }
@@ -374,7 +386,128 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
   }
 
   DBG_T(4);
-  // ---- epilogue ---------------------------------------------------------------------------
+  // ---- lean epilogue for whole tiles ------------------------------------------------------------
+  // Every instruction a wave issues costs the matrix pipe ~4.4 cycles (measured: dummy VALU or SALU
+  // instructions in the K loop cost the same), so the epilogue is written for instruction count: one uniform
+  // 64-bit base per tile, one 32-bit byte offset per lane and output row, the channel blocks of a row as
+  // immediate offsets; the activation / residual combination is selected once per workgroup (uniform branch)
+  // instead of per element.  Same arithmetic, in the same order, as Epilogue::store/finish (common.h).
+  // Partial tiles, missing bias, gates and the sigmoid take the general path below.
+  {
+    const int a1 = p.act1, a2 = p.act2;
+    int kind = -1;  // 0-2: act1 none/leaky/relu, no residual; 3-5: residual then act2 none/relu/leaky; 6: leaky, residual
+    if (p.mul == nullptr && p.bias != nullptr) {
+      if (p.res == nullptr && a2 == AIVC_ACT_NONE && a1 != AIVC_ACT_SIGMOID) kind = a1 == AIVC_ACT_NONE ? 0 : (a1 == AIVC_ACT_LEAKY ? 1 : 2);
+      if (p.res != nullptr && a1 == AIVC_ACT_NONE && a2 != AIVC_ACT_SIGMOID) kind = a2 == AIVC_ACT_NONE ? 3 : (a2 == AIVC_ACT_RELU ? 4 : 5);
+      if (p.res != nullptr && a1 == AIVC_ACT_LEAKY && a2 == AIVC_ACT_NONE) kind = 6;
+    }
+    if ((FUSE || GDN) && kind != 0 && kind != 3) kind = -1;
+    const bool whole = m0 + BM <= M && n0 + BN <= Cout && (!TCONV || W >= BM);
+    if (whole && kind >= 0) {
+      // an opaque zero: nothing below may be scheduled / hoisted above this point (the fused GDN phase before
+      // it is at the register limit of two waves per SIMD)
+      int opq = 0;
+      asm volatile("" : "+s"(opq) : : "memory");
+      const int col = n0 + wn * TN * 32 + (lane & 31) + opq;
+      const int lrow = 4 * (lane >> 5);
+      float cb[TN], cbeta[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        cb[j] = FUSE ? 0.0f : p.bias[col + 32 * j];
+        cbeta[j] = FUSE ? p.gdn_beta[col + 32 * j] : 0.0f;
+      }
+      // element (row k of this wave's sub-tile, channel block j) lives at  base + k * kstep + roff(k) + 128 j  bytes
+      const uint32_t mw = (uint32_t)(m0 + wm * TM * 32 + opq);  // first row of the wave's sub-tile (uniform)
+      ptrdiff_t base_elems;
+      uint32_t lane_off, qx0 = 0;
+      size_t kstep;
+      if constexpr (!TCONV) {
+        base_elems = (ptrdiff_t)mw * Cout;
+        lane_off = (uint32_t)(lrow * Cout + col) * 4u;
+        kstep = (size_t)Cout * 4;
+      } else {
+        // output pixel of GEMM row m: 4 m - 2 (m mod W) + pyc * w_out + pxc   (h_out = 2 H, w_out = 2 W)
+        const uint32_t ml = mw + (uint32_t)lrow;
+        const uint32_t t = __umulhi(ml, a.w_magic);
+        qx0 = ml - t * (uint32_t)W;
+        qx0 = qx0 >= (uint32_t)W ? qx0 - (uint32_t)W : qx0;
+        base_elems = ((ptrdiff_t)4 * mw + pyc * p.w_out + pxc - 2 * W) * Cout;
+        lane_off = (uint32_t)(4 * lrow * Cout + col) * 4u;
+        kstep = (size_t)Cout * 16;
+      }
+      const uint32_t cout8 = (uint32_t)Cout * 8u;
+      char *yb = reinterpret_cast<char *>(p.y + base_elems);
+      const char *rb_ = reinterpret_cast<const char *>(p.res + base_elems);
+      const char *xb = reinterpret_cast<const char *>(p.x + base_elems);
+      const bool inv = FUSE ? p.gdn == 2 : p.mode == AIVC_MODE_IGDN;
+      auto emit = [&](auto KIND, auto INV) {
+        constexpr int KD = decltype(KIND)::value;
+        constexpr bool IV = decltype(INV)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+            uint32_t off = lane_off;
+            if constexpr (TCONV) {
+              uint32_t qx = qx0 + (uint32_t)k;
+              const uint32_t qw = qx - (uint32_t)W;
+              qx = qx < qw ? qx : qw;  // one wrap at most (W >= BM): the unsigned difference is huge when there is none
+              off += ((uint32_t)W - qx) * cout8;
+            }
+            char *yrow = yb + (size_t)k * kstep;
+            const char *rrow = rb_ + (size_t)k * kstep;
+            const char *xrow = xb + (size_t)k * kstep;
+            float rv[TN], xv[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (KD >= 3) rv[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
+              if constexpr (GDN) xv[j] = *reinterpret_cast<const float *>(xrow + off + 128 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v;
+              if constexpr (FUSE) {
+                const float nrm = __builtin_sqrtf(acc2[i][j][r] + cbeta[j]);
+                v = IV ? acc[i][j][r] * nrm : acc[i][j][r] / nrm;
+              } else {
+                v = acc[i][j][r] + cb[j];
+                if constexpr (GDN) {
+                  const float nrm = __builtin_sqrtf(v);
+                  v = IV ? xv[j] * nrm : xv[j] / nrm;
+                }
+              }
+              if constexpr (KD == 1 || KD == 6) v = v > 0.0f ? v : v * 0.01f;
+              if constexpr (KD == 2) v = v > 0.0f ? v : 0.0f;
+              if constexpr (KD >= 3) v = v + rv[j];
+              if constexpr (KD == 4) v = v > 0.0f ? v : 0.0f;
+              if constexpr (KD == 5) v = v > 0.0f ? v : v * 0.01f;
+              *reinterpret_cast<float *>(yrow + off + 128 * j) = v;
+            }
+            // keep the rows apart: interleaving the sqrt / division sequences of many rows costs registers
+            // (the fused kernels sit at the 256-register limit of two waves per SIMD)
+            if constexpr (FUSE || GDN) __builtin_amdgcn_sched_barrier(0);
+          }
+      };
+      using std::integral_constant;
+      if constexpr (FUSE || GDN) {
+        if (kind == 0) { if (inv) emit(integral_constant<int, 0>{}, integral_constant<bool, true>{}); else emit(integral_constant<int, 0>{}, integral_constant<bool, false>{}); }
+        else { if (inv) emit(integral_constant<int, 3>{}, integral_constant<bool, true>{}); else emit(integral_constant<int, 3>{}, integral_constant<bool, false>{}); }
+      } else {
+        switch (kind) {
+          case 0: emit(integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+          case 1: emit(integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+          case 2: emit(integral_constant<int, 2>{}, integral_constant<bool, false>{}); break;
+          case 3: emit(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
+          case 4: emit(integral_constant<int, 4>{}, integral_constant<bool, false>{}); break;
+          case 5: emit(integral_constant<int, 5>{}, integral_constant<bool, false>{}); break;
+          default: emit(integral_constant<int, 6>{}, integral_constant<bool, false>{}); break;
+        }
+      }
+      return;
+    }
+  }
+  // ---- general epilogue -------------------------------------------------------------------------
   // Same arithmetic and order as Epilogue::store/finish (common.h), organised for the instruction cache:
   // the unrolled per-accumulator code holds only branch-free work (bias, GDN division, leaky/relu as a
   // select, gate, residual); the sigmoid activation (an fp64 polynomial, include/aivc_detmath.h) would be

@@ -8,8 +8,9 @@
 //     LDS exactly once per workgroup;
 //   - each thread owns one input position and keeps 4 x c_out accumulators (one per parity class);
 //   - weights are wave-uniform: they arrive through the scalar cache as SGPR operands of v_fma_f32;
-//   - per output value the accumulation is the same (ky, kx) ascending / channel ascending fmaf chain
-//     as every other implementation (taps outside the image contribute fmaf(0, w, acc) = acc).
+//   - per output value the accumulation is the same fmaf chain as every other implementation: the taps of the
+//     class in (ky, kx) order, 8 channels at a time in AIVC_K_ORDER (include/aivc_hip.h); taps outside the
+//     image contribute fmaf(0, w, acc) = acc.
 #include <stdlib.h>
 
 #include "common.h"
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(TH * 16) void thin_tconv_kernel(aivc_conv_params p)
   for (int c0 = 0; c0 < 4; c0 += PAR)
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    for (int ci = 0; ci < Cin; ci += 4) {
+    for (int ci = 0; ci < Cin; ci += 8) {  // a group of 8 channels, accumulated in AIVC_K_ORDER (0,4,1,5,2,6,3,7)
 #pragma unroll
       for (int c = c0; c < c0 + PAR; ++c) {
         const int pyc = c >> 1, pxc = c & 1;
@@ -87,16 +88,21 @@ __global__ __launch_bounds__(TH * 16) void thin_tconv_kernel(aivc_conv_params p)
         if (t < class_ntaps<KS>(pyc) * nx) {
           const int ky = class_tap<KS>(pyc, t / nx), kx = class_tap<KS>(pxc, t % nx);
           const int dy = (pyc + TPAD - ky) >> 1, dx = (pxc + TPAD - kx) >> 1;
-          const float4 xv = *reinterpret_cast<const float4 *>(center + (dy * PW + dx) * stride_px + ci);
+          const float4 x0 = *reinterpret_cast<const float4 *>(center + (dy * PW + dx) * stride_px + ci);
+          const float4 x1 = *reinterpret_cast<const float4 *>(center + (dy * PW + dx) * stride_px + ci + 4);
           const float *wt = p.w + (size_t)(ky * KS + kx) * Cin + ci;
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
             const float *wo = wt + (size_t)o * KS * KS * Cin;
             float a = acc[c][o];
-            a = __builtin_fmaf(xv.x, wo[0], a);
-            a = __builtin_fmaf(xv.y, wo[1], a);
-            a = __builtin_fmaf(xv.z, wo[2], a);
-            a = __builtin_fmaf(xv.w, wo[3], a);
+            a = __builtin_fmaf(x0.x, wo[0], a);
+            a = __builtin_fmaf(x1.x, wo[4], a);
+            a = __builtin_fmaf(x0.y, wo[1], a);
+            a = __builtin_fmaf(x1.y, wo[5], a);
+            a = __builtin_fmaf(x0.z, wo[2], a);
+            a = __builtin_fmaf(x1.z, wo[6], a);
+            a = __builtin_fmaf(x0.w, wo[3], a);
+            a = __builtin_fmaf(x1.w, wo[7], a);
             acc[c][o] = a;
           }
         }
@@ -119,12 +125,19 @@ __global__ __launch_bounds__(TH * 16) void thin_tconv_kernel(aivc_conv_params p)
 // structure lives in the B operand: B[(dy, dx, ci)][class, o] = w[o][ky][kx][ci] with
 // ky = pyc + TPAD - 2 dy, kx = pxc + TPAD - 2 dx when that is a kernel tap of the class, else 0.
 // Walking the neighbourhood with dy, dx DESCENDING makes ky, kx ascend for every class at once, so each
-// output sees exactly the oracle's (ky, kx, ci)-ascending fmaf chain with exact no-ops (fmaf(x, 0, acc))
-// in between.  v_mfma_f32_16x16x4_f32 accumulates its 4 k-slots in order (tools/mfma_probe.hip checks it
-// against an fmaf chain), lane group g = lane / 16 supplies slot g, so inside every group of 16 channels
-// LDS position 4 g + e holds channel 4 e + g: one ds_read_b128 feeds 4 consecutive MFMA steps.
+// output sees exactly the contract's fmaf chain (taps of its class in (ky, kx) order, channels in groups of 8
+// in AIVC_K_ORDER) with exact no-ops (fmaf(x, 0, acc)) in between.  v_mfma_f32_16x16x4_f32 accumulates its 4
+// k-slots in order (tools/mfma_probe.hip checks it against an fmaf chain), lane group g = lane / 16 supplies
+// slot g, so inside every group of 16 channels LDS position 4 g + e holds channel thin_chan(g, e): one
+// ds_read_b128 feeds 4 consecutive MFMA steps.
 // 52 % (c_out 3) / 39 % (c_out 6) of the MFMA work is useful, still 2-3x the VALU kernel above.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// Channel (inside a group of 16) that k-slot g = lane / 16 multiplies at MFMA step e.  The contract order of
+// include/aivc_hip.h inside 16 channels is 0 4 1 5 | 2 6 3 7 | 8 12 9 13 | 10 14 11 15 (two groups of 8 in
+// AIVC_K_ORDER); v_mfma_f32_16x16x4_f32 accumulates its 4 slots in order, so step e takes the e-th quadruple
+// and slot g its g-th entry.
+__device__ __host__ constexpr int thin_chan(int g, int e) { return 8 * (e >> 1) + AIVC_K_ORDER(4 * (e & 1) + g); }
 
 // Persistent workgroups (one per CU, 8 wavefronts): the B operand of a wavefront -- its 16 output columns
 // over all K = ND^2 * c_in -- is gathered from the weight tensor ONCE into registers (144 VGPRs at
@@ -162,10 +175,10 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
     const int dy = HI - t / ND, dx = HI - t % ND;
     const int ky = pyc + TPAD - 2 * dy, kx = pxc + TPAD - 2 * dx;
     const bool ok = colok && ky >= 0 && ky < KS && kx >= 0 && kx < KS;
-    const float *src = p.w + (size_t)((o * KS + (ok ? ky : 0)) * KS + (ok ? kx : 0)) * Cin + j16 * 16 + g;
+    const float *src = p.w + (size_t)((o * KS + (ok ? ky : 0)) * KS + (ok ? kx : 0)) * Cin + j16 * 16;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v = src[4 * e];
+      const float v = src[thin_chan(g, e)];
       breg[step][e] = ok ? v : 0.0f;
     }
   }
@@ -202,11 +215,11 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
     for (int u = 0; u < UPT; ++u) {
       const int i = tid + 512 * u;
       if (i < UNITS) {
-        float *dst = buf + (i / G16) * SPX + (i % G16) * 16;  // position 4 g + e <- channel 4 e + g
-        *reinterpret_cast<float4 *>(dst) = make_float4(sreg[u][0].x, sreg[u][1].x, sreg[u][2].x, sreg[u][3].x);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(sreg[u][0].y, sreg[u][1].y, sreg[u][2].y, sreg[u][3].y);
-        *reinterpret_cast<float4 *>(dst + 8) = make_float4(sreg[u][0].z, sreg[u][1].z, sreg[u][2].z, sreg[u][3].z);
-        *reinterpret_cast<float4 *>(dst + 12) = make_float4(sreg[u][0].w, sreg[u][1].w, sreg[u][2].w, sreg[u][3].w);
+        float *dst = buf + (i / G16) * SPX + (i % G16) * 16;  // position 4 g + e <- channel thin_chan(g, e)
+        *reinterpret_cast<float4 *>(dst) = make_float4(sreg[u][0].x, sreg[u][0].z, sreg[u][2].x, sreg[u][2].z);       // 0 2 8 10
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(sreg[u][1].x, sreg[u][1].z, sreg[u][3].x, sreg[u][3].z);   // 4 6 12 14
+        *reinterpret_cast<float4 *>(dst + 8) = make_float4(sreg[u][0].y, sreg[u][0].w, sreg[u][2].y, sreg[u][2].w);   // 1 3 9 11
+        *reinterpret_cast<float4 *>(dst + 12) = make_float4(sreg[u][1].y, sreg[u][1].w, sreg[u][3].y, sreg[u][3].w);  // 5 7 13 15
       }
     }
   };
@@ -314,7 +327,7 @@ bool conv2d_thin_supported(const aivc_conv_params &p) {
   if (p.mode != AIVC_MODE_TCONV || p.gdn) return false;
   if (p.c_out != 3 && p.c_out != 6) return false;
   if (p.ksize != 3 && p.ksize != 5) return false;
-  return p.c_in % 4 == 0 && p.c_in >= 16 && p.c_in <= 128;
+  return p.c_in % 8 == 0 && p.c_in >= 16 && p.c_in <= 128;
 }
 
 template <int KS, int CO>

@@ -20,11 +20,15 @@
  * it is test infrastructure only.
  *
  * Arithmetic contract (what "bit exact" means for the fp32 ops):
- *   conv-like ops accumulate   acc = fmaf(a, w, acc)   starting from +0.0f, iterating kernel
- *   taps in (ky, kx) ascending order and, inside a tap, stored input channels ascending;
- *   then v = acc + bias, then the epilogue in the order documented at aivc_conv2d.
- *   v_mfma_f32_32x32x2_f32 implements exactly this k-ordered fmaf chain, so the MFMA
- *   kernels, the scalar HIP kernels and the CPU oracle agree bitwise.
+ *   conv-like ops accumulate   acc = fmaf(a, w, acc)   starting from +0.0f over the reduction
+ *   index kk = t * c_in + ci, where t counts the kernel taps in (ky, kx) ascending order (for a
+ *   transposed conv: the taps of the output pixel's parity class, out-of-image taps keeping their
+ *   place with a zero input) and ci the stored input channels.  kk is walked in groups of 8
+ *   (the last group zero padded), inside a group in the order 0, 4, 1, 5, 2, 6, 3, 7
+ *   (AIVC_K_ORDER): the order in which v_mfma_f32_32x32x2_f32 consumes an operand row held in
+ *   natural K order, so the MFMA kernels need no operand shuffling; the scalar HIP kernels and
+ *   the CPU oracle walk the same order and all agree bitwise.  A zero term is an exact no-op.
+ *   Then v = acc + bias, then the epilogue in the order documented at aivc_conv2d.
  *   Transcendentals (exp for sigma / sigmoid, expm1 for the Laplace CDF, the factorised
  *   prior's softplus/tanh/sigmoid) are evaluated by a fixed fp64 polynomial scheme
  *   ("det_exp" family) and rounded once to fp32, identically on host and device.
@@ -38,6 +42,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* position inside a group of 8 reduction indices visited at step i (see the arithmetic contract above) */
+#define AIVC_K_ORDER(i) ((((i) & 1) << 2) | ((i) >> 1))
 
 typedef void *aivc_stream_t; /* hipStream_t */
 
@@ -100,7 +107,7 @@ typedef struct aivc_conv_params {
 } aivc_conv_params;
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
- *                     s_i = fmaf chain over j ascending of (t_j, gamma[i][j]) from +0, then + beta[i];
+ *                     s_i = fmaf chain over j (in AIVC_K_ORDER) of (t_j, gamma[i][j]) from +0, then + beta[i];
  *                     v_i = gdn == 1 ? v_i / sqrtf(s_i) : v_i * sqrtf(s_i)
  *                   -- bit identical to a CONV launch followed by a GDN/IGDN-mode launch];
  *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v).

@@ -88,7 +88,7 @@ def _gain(net, frame_type, mode, idx_rate=0):
 
 def _shortcut(net, in_shortcut, h_y, w_y):
     if in_shortcut is not None and net['g_a_ref'] is not None:
-        return O.run_layer(net['g_a_ref'], in_shortcut)[:, :h_y, :w_y, :]
+        return O.run_layer(net['g_a_ref'], in_shortcut, cmap=O.image_cmap(in_shortcut.shape[-1] // 3))[:, :h_y, :w_y, :]
     return np.zeros((1, h_y, w_y, net['c_short']), np.float32)
 
 
@@ -105,7 +105,7 @@ def _y_section(sigma, q_y):
 
 
 def cond_encode(net, x_in, in_shortcut, frame_type, idx_rate=0.):
-    y = O.run_layer(net['g_a'], x_in)
+    y = O.run_layer(net['g_a'], x_in, cmap=O.image_cmap(x_in.shape[-1] // 3))  # images: 3 channels stored as 4
     y = O.channel_gain(y, _gain(net, frame_type, 'enc', idx_rate))
     z = O.run_layer(net['h_a'], y)
     q_z, z_hat = O.quantize_center(z)

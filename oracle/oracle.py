@@ -91,9 +91,21 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
 
 
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
-           res=None, gdn=None):
-    """gdn = (beta_eff, gamma_eff, inverse): (inverse) GDN fused after the bias"""
+           res=None, gdn=None, cmap=None):
+    """gdn = (beta_eff, gamma_eff, inverse): (inverse) GDN fused after the bias.
+    cmap: stored position of every input channel (default: the first ones, zero padding behind).  The
+    accumulation order of the contract is defined on STORED positions (groups of 8 in AIVC_K_ORDER), so an
+    input the codec stores as 3-channel images each padded to 4 must be laid out the same way here."""
     x = _f32(x)
+    if cmap is not None:
+        cmap = list(cmap)
+        c_st = (max(cmap) + 4) // 4 * 4
+        xs = np.zeros(x.shape[:-1] + (c_st,), np.float32)
+        xs[..., cmap] = x
+        w_ohwi = _f32(w_ohwi)
+        ws = np.zeros(w_ohwi.shape[:3] + (c_st,), np.float32)
+        ws[..., cmap] = w_ohwi[..., :len(cmap)]
+        x, w_ohwi = xs, ws
     n, h, w_, c = x.shape
     if c % 4:
         x = pad_channels(x, (c + 3) // 4 * 4)
@@ -374,23 +386,33 @@ def _gdn_from_spec(g, x, res=None):
     return gdn(x, be, ge, inverse=g['inverse'], res=res)
 
 
-def run_layer(spec, x, res=None):
+def image_cmap(n_images):
+    """stored channel positions of n 3-channel images, each padded to 4 (the codec's layout of its image
+    inputs: aivc_amd/codec.py FrameCodec._images)"""
+    return tuple(4 * i + c for i in range(n_images) for c in range(3))
+
+
+def run_layer(spec, x, res=None, cmap=None):
     """Evaluate one layer spec.  `res` (optional) is added to the output (used by the residual
-    blocks to express `aux(x) + layers(x)` with the same operand order as the fused kernels)."""
+    blocks to express `aux(x) + layers(x)` with the same operand order as the fused kernels).
+    cmap: stored layout of the input channels, for the first conv of a transform (see conv2d)."""
     t = spec['type']
     if t == 'Sequential':
-        for s in spec['layers'][:-1]:
+        if len(spec['layers']) == 1:
+            return run_layer(spec['layers'][0], x, res=res, cmap=cmap)
+        x = run_layer(spec['layers'][0], x, cmap=cmap)
+        for s in spec['layers'][1:-1]:
             x = run_layer(s, x)
-        return run_layer(spec['layers'][-1], x, res=res) if spec['layers'] else x
+        return run_layer(spec['layers'][-1], x, res=res)
     if t == 'CustomConvLayer':  # custom_conv_layers.py:129-180
         k = spec['k']
         w = pack_weight(spec['weight'])
         nl = spec['nl']
         if nl in ('gdn', 'gdn_inverse'):
-            y = conv2d(x, w, spec.get('bias'), stride=spec['stride'], pad=k // 2)
+            y = conv2d(x, w, spec.get('bias'), stride=spec['stride'], pad=k // 2, cmap=cmap)
             return _gdn_from_spec(spec['gdn'], y, res=res)
         return conv2d(x, w, spec.get('bias'), stride=spec['stride'], pad=k // 2, act1=_ACT[nl],
-                      res=res)
+                      res=res, cmap=cmap)
     if t == 'UpscalingLayer':  # custom_conv_layers.py:183-253
         w = pack_weight(spec['weight'], transposed=True)
         nl = spec['nl']
