@@ -187,17 +187,24 @@ class FrameCodec:
             pool.append(torch.cuda.Stream(priority=-1))
         return pool[:k]
 
-    def _chunks(self, gop, level, unit_ids):
+    def _chunks(self, gop, level, unit_ids, shard=None):
         """(frame type, [(unit, frame name), ...]) batches of at most max_batch same-type frames of one
-        dependency level (a level of a chained GOP mixes P and B frames)."""
+        dependency level (a level of a chained GOP mixes P and B frames); with a shard, this rank's share."""
         for ftype in sorted({gop[f]['type'] for f in level}):
             items = [(u, f) for u in unit_ids for f in level if gop[f]['type'] == ftype]
+            if shard is not None:
+                items = shard.mine(items)
             for s in range(0, len(items), self.max_batch):
                 yield ftype, items[s:s + self.max_batch]
 
-    def encode_units(self, units, gop_name, idx_rate=0.):
+    def encode_units(self, units, gop_name, idx_rate=0., shard=None):
         """units: list of frame lists (display order, each len == len(GOP struct)).
-        -> ([gop bytes per unit], [reconstructions per unit], data_dim)"""
+        -> ([gop bytes per unit], [reconstructions per unit], data_dim)
+        shard (aivc_amd.parallel.ClipShard, optional): the frames of every dependency level are spread over the
+        ranks of this process' group; each rank codes `shard.mine(items)` and the new 8-bit reconstructions are
+        exchanged once per level (they are the references of the next levels).  Stream scheduling is the
+        single-GPU one; the frame bitstreams are gathered once, at the end.  Every rank of the group returns
+        the same blobs -- identical to a single-process run."""
         gop = generate_gop_struct(gop_name)
         names = sorted(gop, key=frame_index)
         rec = [dict() for _ in units]
@@ -206,6 +213,7 @@ class FrameCodec:
         sides = self._side_streams(self.entropy_streams)
         jobs = []
         waiting = None  # (items, sections, flags on their way to the host) of the previous level
+        split = shard is not None and shard.R > 1
 
         def flush(li):
             # the levels' coder launches are independent of each other: rotate the stream so that a level with
@@ -218,7 +226,7 @@ class FrameCodec:
         for li, level in enumerate(coding_levels(gop)):
             n_levels = li + 1
             pending = []
-            for ftype, chunk in self._chunks(gop, level, range(len(units))):
+            for ftype, chunk in self._chunks(gop, level, range(len(units)), shard):
                 out = self.encode_batch([units[u][frame_index(f)] for u, f in chunk],
                                         [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
                                         [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate)
@@ -231,21 +239,36 @@ class FrameCodec:
             # after the next level's transforms are queued, so the main stream never drains on that wait
             all_secs = [s for _, secs in pending for s in secs]
             items = [it for chunk, _ in pending for it in chunk]
-            prep = prepare_finalize(all_secs)
+            prep = prepare_finalize(all_secs) if all_secs else None
+            if split:  # every rank of the group needs this level's reconstructions before the next level
+                h, w = units[0][0]['y'].shape[-2:]
+                for ftype in sorted({gop[f]['type'] for f in level}):
+                    every = [(u, f) for u in range(len(units)) for f in level if gop[f]['type'] == ftype]
+                    got = shard.exchange_frames(every, [rec[u][f] for u, f in shard.mine(every)], h, w,
+                                                units[0][0]['y'].device)
+                    for (u, f), r in zip(every, got):
+                        rec[u][f] = r
             if waiting is not None:
                 flush(li - 1)
-            waiting = (items, all_secs, prep)
+            waiting = (items, all_secs, prep) if all_secs else None
         if waiting is not None:
             flush(n_levels - 1)
         for items, job in jobs:
             for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b
+        if split:
+            keys = [(u, f) for u in range(len(units)) for f in names]
+            allb = shard.gather_bytes({k: fbytes[k[0]][k[1]] for k in keys if k[1] in fbytes[k[0]]}, keys)
+            for (u, f), b in allb.items():
+                fbytes[u][f] = b
+            data_dim = shard.agree(data_dim)
         head = hdr.gop_header_bytes(gop_name, idx_rate)
         blobs = [container.pack_gop(head, [fbytes[u][f] for f in names]) for u in range(len(units))]
         return blobs, [[rec[u][f] for f in names] for u in range(len(units))], data_dim
 
-    def decode_units(self, gop_blobs, data_dim, device=None):
-        """-> [reconstructions (display order) per unit].
+    def decode_units(self, gop_blobs, data_dim, device=None, shard=None):
+        """-> [reconstructions (display order) per unit].  shard: as in encode_units (the entropy stage only runs
+        for this rank's frames; one exchange of the new reconstructions per level).
         Stage 1 entropy-decodes EVERY frame of every unit (entropy_chunk frames at a time: that many
         range-coder streams run concurrently, one wavefront each; the serial coder is off the
         frame-to-frame critical path).  Stage 2 reconstructs level by level in batches."""
@@ -270,6 +293,8 @@ class FrameCodec:
             def issue_entropy(level):
                 for ftype in sorted({gop[f]['type'] for f in level}):
                     items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
+                    if shard is not None:
+                        items = shard.mine(items)
                     for s0 in range(0, len(items), self.entropy_chunk):
                         chunk = items[s0:s0 + self.entropy_chunk]
                         pair = [sides[(rr[0] + k) % len(sides)] for k in range(2)]
@@ -290,7 +315,7 @@ class FrameCodec:
             for li, level in enumerate(levels):
                 if li + ahead < len(levels):
                     issue_entropy(levels[li + ahead])
-                for ftype, chunk in self._chunks(gop, level, members):
+                for ftype, chunk in self._chunks(gop, level, members, shard):
                     for ev in {id(e): e for it in chunk for e in ready[it]}.values():
                         main.wait_event(ev)
                     yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
@@ -300,6 +325,14 @@ class FrameCodec:
                     for (i, f), r in zip(chunk, dec):
                         rec[i][f] = r
                         del lat[(i, f)]
+                if shard is not None and shard.R > 1:
+                    h, w = data_dim['x']
+                    for ftype in sorted({gop[f]['type'] for f in level}):
+                        every = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
+                        got = shard.exchange_frames(every, [rec[i][f] for i, f in shard.mine(every)], h, w,
+                                                    device or torch.device('cuda'))
+                        for (i, f), r in zip(every, got):
+                            rec[i][f] = r
             for i in members:
                 out[i] = [rec[i][f] for f in names]
         return out

@@ -17,6 +17,18 @@ FRAME_I, FRAME_P, FRAME_B = abi.FRAME_I, abi.FRAME_P, abi.FRAME_B
 
 # when bench.py sets this to a list, every aivc_conv2d launch is bracketed by HIP events
 PROFILE = None
+# likewise for the HBM-bound stages: (name, algorithmic bytes, event, event) per launch
+PROFILE_HBM = None
+
+
+def _hbm_profiled(name, nbytes, launch):
+    if PROFILE_HBM is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE_HBM.append((name, float(nbytes), e0, e1))
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -177,8 +189,10 @@ def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
     if out is None:
         out = torch.zeros((n, h, w, c_store), dtype=torch.float32, device=y.device)
     zero_pad = 1 if out.shape[-1] >= c_off + 4 else 0
-    call('aivc_yuv420u8_to_444' if u8 else 'aivc_yuv420_to_444', _p(y), _p(u), _p(v), n, h, w,
-         _p(out), out.shape[-1], c_off, zero_pad, _stream())
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    _hbm_profiled('yuv420_to_444', n * ((h * w + 2 * hc * wc) * (1 if u8 else 4) + h * w * 4 * (3 + zero_pad)),
+                  lambda: call('aivc_yuv420u8_to_444' if u8 else 'aivc_yuv420_to_444', _p(y), _p(u), _p(v), n, h, w,
+                               _p(out), out.shape[-1], c_off, zero_pad, _stream()))
     return out
 
 
@@ -198,8 +212,11 @@ def frame_to_yuv420(x, h, w, skip=None, want_float=True, want_u8=True):
         b = [torch.empty((n, h, w), dtype=torch.uint8, device=dev),
              torch.empty((n, hc, wc), dtype=torch.uint8, device=dev),
              torch.empty((n, hc, wc), dtype=torch.uint8, device=dev)]
-    call('aivc_frame_to_yuv420', _p(x), n, hx, wx, cx, _p(skip), 0 if skip is None else skip.shape[-1],
-         h, w, _p(f[0]), _p(f[1]), _p(f[2]), _p(b[0]), _p(b[1]), _p(b[2]), _stream())
+    # algorithmic bytes: the 3 real channels of x (and of skip) over the frame, the 4:2:0 planes out
+    nb = n * (h * w * 3 * 4 * (2 if skip is not None else 1) + (h * w + 2 * hc * wc) * ((4 if want_float else 0) + (1 if want_u8 else 0)))
+    _hbm_profiled('frame_to_yuv420', nb,
+                  lambda: call('aivc_frame_to_yuv420', _p(x), n, hx, wx, cx, _p(skip), 0 if skip is None else skip.shape[-1],
+                               h, w, _p(f[0]), _p(f[1]), _p(f[2]), _p(b[0]), _p(b[1]), _p(b[2]), _stream()))
     return tuple(f), tuple(b)
 
 
@@ -231,8 +248,12 @@ def warp_blend(mof, prev, nxt, h, w, frame_type, co=4, want_aux=False):
         xw = torch.empty_like(pred)
         alpha = torch.empty((n, h, w), dtype=torch.float32, device=dev)
         beta = torch.empty((n, h, w), dtype=torch.float32, device=dev)
-    call('aivc_warp_blend', _p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
-         int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha), _p(beta), _stream())
+    # algorithmic bytes: the 6 MOFNet maps, 3 channels of each reference used, pred + skip out
+    n_ref = 2 if int(frame_type) == FRAME_B else 1
+    nb = n * h * w * 4 * (6 + 3 * n_ref + 2 * co + ((co + 2) if want_aux else 0))
+    _hbm_profiled('warp_blend', nb,
+                  lambda: call('aivc_warp_blend', _p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
+                               int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha), _p(beta), _stream()))
     return {'pred': pred, 'skip': skip, 'x_warp': xw, 'alpha': alpha, 'beta': beta}
 
 
@@ -315,8 +336,9 @@ def laplace_cdf_rows(sigma, maps, out=None, row_off=0):
     if out is None:
         out = torch.empty((len(maps) * npix, abi.CDF_ROW), dtype=torch.int16, device=sigma.device)
         row_off = 0
-    call('aivc_laplace_cdf_rows', _p(sigma), npix, c, C.byref(ml), out.data_ptr() + 2 * row_off * abi.CDF_ROW,
-         _stream())
+    _hbm_profiled('laplace_cdf_rows', len(maps) * npix * (4 + 2 * abi.CDF_ROW),
+                  lambda: call('aivc_laplace_cdf_rows', _p(sigma), npix, c, C.byref(ml),
+                               out.data_ptr() + 2 * row_off * abi.CDF_ROW, _stream()))
     return out
 
 

@@ -92,91 +92,215 @@ def decode_video_sharded(frame_codec, blob, device=None):
     return out
 
 
-# ---- temporal-layer sharding inside the units -----------------------------------------
-# When there are fewer intra-period units than GPUs (BASELINE configs[3]: 4 units for 8 GPUs,
-# configs[4]: 1 unit) the frames of one dependency level are spread over the ranks instead: they
-# only depend on earlier levels.  After each level every rank needs the new 8-bit reconstructions
-# (they are the references of the next levels): one all_gather of uint8 4:2:0 frames per level
-# (3.1 MB per 1080p frame over xGMI), plus the frame bitstreams (bytes) gathered as objects.
-def _frames_to_tensor(recs, device):
-    """list of plane dicts -> uint8 [k, bytes_per_frame]"""
-    return torch.stack([torch.cat([r[k].reshape(-1) for k in 'yuv']) for r in recs]).to(device)
+# ---- one clip over all GPUs: unit groups x temporal-layer sharding ---------------------------
+# BASELINE configs[3] is ONE 128-frame 1080p clip on 8 GPUs: 4 intra-period units.  Units go to
+# G = min(world, n_units) groups of R = world // G ranks; inside a group the frames of one dependency level
+# (they only depend on earlier levels) are dealt round-robin to its ranks.  The only exchanges are
+#   * per level: one all_gather of the new 8-bit reconstructions inside the group (3.1 MB per 1080p frame over
+#     xGMI) -- they are the references of the next levels;
+#   * once per clip: the frame bitstreams inside the group, then the GOP records to every rank
+# all as TENSOR collectives (uint8 payload + int64 lengths): no pickling, no host round trip on RCCL.
+# Output bytes are identical to a single process by construction (tests: gloo on CPU with the oracle as the frame
+# coder, gloo + two processes on one GPU with the HIP codec).
+def _comm_device(group=None, device=None):
+    """tensors handed to collectives: CUDA under RCCL ('nccl'), host memory under gloo"""
+    if dist.get_backend(group) == 'nccl':
+        return device if device is not None and device.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
 
 
-def _tensor_to_frames(t, h, w, device):
-    hc, wc = (h + 1) // 2, (w + 1) // 2
-    out = []
-    for row in t:
-        row = row.to(device)
-        out.append({'y': row[:h * w].view(1, h, w), 'u': row[h * w:h * w + hc * wc].view(1, hc, wc),
-                    'v': row[h * w + hc * wc:h * w + 2 * hc * wc].view(1, hc, wc)})
-    return out
+class ClipShard:
+    """Partition of one clip's work over the ranks.  Collective: every rank must construct it (sub-groups are
+    created with dist.new_group in the same order everywhere)."""
+
+    def __init__(self, n_units, device=None):
+        self.rank, self.world = rank_world()
+        self.G = max(1, min(self.world, n_units))
+        self.R = max(1, self.world // self.G)
+        active = self.G * self.R  # ranks beyond (world not a multiple of G) idle
+        self.active = self.rank < active
+        self.group_id = self.rank // self.R if self.active else None
+        self.local = self.rank % self.R if self.active else 0
+        self.units = [u for u in range(n_units) if self.active and u % self.G == self.group_id]
+        self.n_units = n_units
+        self.device = device
+        self.pg = None
+        if self.world > 1:
+            for g in range(self.G):
+                ranks = list(range(g * self.R, (g + 1) * self.R))
+                pg = dist.new_group(ranks) if self.R > 1 else None
+                if g == self.group_id:
+                    self.pg = pg
+        self.leaders = [g * self.R for g in range(self.G)]
+
+    # ---- who codes what ---------------------------------------------------------------------------------
+    def mine(self, items):
+        return items[self.local::self.R]
+
+    # ---- exchanges inside the group ------------------------------------------------------------------------
+    def exchange_frames(self, items, my_recs, h, w, device):
+        """items: every frame of a level (same order on all ranks of the group); my_recs: reconstructions of
+        self.mine(items).  -> reconstructions of all items (uint8 plane dicts on `device`)."""
+        if self.R == 1:
+            return my_recs
+        cdev = _comm_device(self.pg, device)
+        per = (len(items) + self.R - 1) // self.R  # every rank sends `per` frames (zero padded)
+        hc, wc = (h + 1) // 2, (w + 1) // 2
+        fsz = h * w + 2 * hc * wc
+        send = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
+        for i, r in enumerate(my_recs):
+            send[i] = torch.cat([r[k].reshape(-1) for k in 'yuv']).to(cdev)
+        recv = torch.empty((self.R * per, fsz), dtype=torch.uint8, device=cdev)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.pg)  # flat: gloo wants 1-D
+        recv = recv.to(device)
+        out = [None] * len(items)
+        for j in range(len(items)):
+            row = recv[(j % self.R) * per + j // self.R]
+            out[j] = {'y': row[:h * w].view(1, h, w), 'u': row[h * w:h * w + hc * wc].view(1, hc, wc),
+                      'v': row[h * w + hc * wc:].view(1, hc, wc)}
+        return out
+
+    def _gather_bytes(self, mine, keys, group, n_ranks, device=None):
+        """mine: {key: bytes} held by this rank; keys: ordered list of all keys (same on all ranks).
+        -> {key: bytes} complete on every rank of `group`.  Two tensor collectives: lengths, padded payload."""
+        cdev = _comm_device(group, device or self.device)
+        lens = torch.tensor([len(mine[k]) if k in mine else -1 for k in keys], dtype=torch.int64, device=cdev)
+        all_lens = torch.empty((n_ranks, len(keys)), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_lens.view(-1), lens, group=group)
+        all_lens = all_lens.cpu()
+        totals = all_lens.clamp_min(0).sum(dim=1)
+        cap = max(int(totals.max()), 1)
+        payload = bytearray()
+        for k in keys:
+            if k in mine:
+                payload += mine[k]
+        buf = torch.zeros(cap, dtype=torch.uint8)
+        if payload:
+            buf[:len(payload)] = torch.frombuffer(payload, dtype=torch.uint8)
+        buf = buf.to(cdev)
+        recv = torch.empty((n_ranks, cap), dtype=torch.uint8, device=cdev)
+        dist.all_gather_into_tensor(recv.view(-1), buf, group=group)
+        recv = recv.cpu().numpy()
+        out = {}
+        for r in range(n_ranks):
+            pos = 0
+            for j, k in enumerate(keys):
+                n = int(all_lens[r, j])
+                if n >= 0:
+                    out.setdefault(k, recv[r, pos:pos + n].tobytes())
+                    pos += n
+        return out
+
+    def gather_bytes(self, mine, keys):
+        """frame bitstreams inside the group"""
+        if self.R == 1:
+            return dict(mine)
+        return self._gather_bytes(mine, keys, self.pg, self.R)
+
+    def agree(self, data_dim):
+        """latent sizes are known to the ranks that coded a frame; every rank of the group returns them"""
+        if self.R == 1:
+            return data_dim
+        cdev = _comm_device(self.pg, self.device)
+        v = [-1] * 6 if data_dim is None else [*data_dim['x'], *data_dim['y'], *data_dim['z']]
+        t = torch.tensor(v, dtype=torch.int64, device=cdev)
+        allv = torch.empty((self.R, 6), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(allv.view(-1), t, group=self.pg)
+        v = [int(x) for x in allv.cpu().max(dim=0).values]
+        return {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
+
+    # ---- across the groups ------------------------------------------------------------------------------------
+    def gather_units(self, blobs_by_unit, data_dim=None):
+        """blobs_by_unit: {unit: GOP record} of this rank's group.  -> ([record per unit], data_dim) on EVERY rank."""
+        if self.world == 1:
+            return [blobs_by_unit[u] for u in range(self.n_units)], data_dim
+        keys = list(range(self.n_units)) + ['dd']
+        mine = {}
+        if self.active and self.local == 0:  # one contributor per group
+            mine = dict(blobs_by_unit)
+            if data_dim is not None and self.group_id == 0:
+                mine['dd'] = b''.join(int(x).to_bytes(4, 'big') for x in (*data_dim['x'], *data_dim['y'], *data_dim['z']))
+        allb = self._gather_bytes(mine, keys, None, self.world)
+        dd = None
+        if 'dd' in allb:
+            v = [int.from_bytes(allb['dd'][i:i + 4], 'big') for i in range(0, 24, 4)]
+            dd = {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
+        return [allb[u] for u in range(self.n_units)], dd
 
 
-def encode_units_level_sharded(frame_codec, units, gop_name, idx_rate=0., comm_device=None):
-    """Like FrameCodec.encode_units, with the frames of every dependency level distributed
-    round-robin over the ranks.  Every rank passes the same `units` and returns the same
-    (gop blobs, data_dim); bytes are identical to a single-process run."""
+def encode_clip(frame_codec, units, gop_name, idx_rate=0., shard=None):
+    """Strong scaling: ONE clip (list of intra-period units, every rank passes the same frames) over all ranks.
+    -> ([GOP record per unit], data_dim) on every rank; bytes identical to frame_codec.encode_units(units)."""
+    shard = shard or ClipShard(len(units), units[0][0]['y'].device)
+    mine = {}
+    data_dim = None
+    if shard.units:
+        blobs, _, data_dim = frame_codec.encode_units([units[u] for u in shard.units], gop_name, idx_rate, shard=shard)
+        mine = dict(zip(shard.units, blobs))
+    return shard.gather_units(mine, data_dim)
+
+
+def decode_clip(frame_codec, gop_blobs, data_dim, device=None, shard=None):
+    """-> {unit: [reconstructions in display order]} for the units of this rank's group (the frames stay on the
+    GPUs that decoded them; every rank of a group holds all frames of the group's units)."""
+    shard = shard or ClipShard(len(gop_blobs), device)
+    if not shard.units:
+        return {}
+    recs = frame_codec.decode_units([gop_blobs[u] for u in shard.units], data_dim, device, shard=shard)
+    return dict(zip(shard.units, recs))
+
+
+# ---- generic level-by-level drivers (any frame coder with encode_batch / decode_batch: the CPU tests run them
+# with the oracle behind that interface; the HIP codec has the same logic inside FrameCodec.encode_units /
+# decode_units, where it keeps the single-GPU stream scheduling) ----------------------------------------------------
+def encode_units_level_sharded(frame_codec, units, gop_name, idx_rate=0., shard=None):
+    """Every rank passes the same `units` (those of its group) and returns the same (gop blobs, data_dim)."""
     from .codec import frame_index
     from .func_util.GOP_structure import coding_levels, generate_gop_struct
     from .real_life import cat_binary_files as container
     from .real_life import header as hdr
     from .real_life.bitstream import finalize_frames
-    rank, world = rank_world()
+    shard = shard or _whole_world_shard(units[0][0]['y'].device)
     gop = generate_gop_struct(gop_name)
     names = sorted(gop, key=frame_index)
     rec = [dict() for _ in units]
-    fbytes = [dict() for _ in units]
+    fbytes = {}
     data_dim = None
     h, w = units[0][0]['y'].shape[-2:]
     dev = units[0][0]['y'].device
-    comm_device = comm_device or dev
     for level in coding_levels(gop):
         for ftype in sorted({gop[f]['type'] for f in level}):
             items = [(u, f) for u in range(len(units)) for f in level if gop[f]['type'] == ftype]
-            mine = items[rank::world]
-            my_bytes, my_recs = [], []
+            mine = shard.mine(items)
+            my_recs = []
             for s in range(0, len(mine), frame_codec.max_batch):
                 chunk = mine[s:s + frame_codec.max_batch]
                 out = frame_codec.encode_batch([units[u][frame_index(f)] for u, f in chunk],
                                                [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
                                                [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate)
                 data_dim = out['data_dim']
-                my_bytes += finalize_frames(out['sections'])
+                for it, b in zip(chunk, finalize_frames(out['sections'])):
+                    fbytes[it] = b
                 my_recs += out['rec']
-            if world == 1:
-                all_bytes, all_recs = [my_bytes], [my_recs]
-            else:
-                per = (len(items) + world - 1) // world  # every rank sends `per` frames (zero padded)
-                fsz = h * w + 2 * ((h + 1) // 2) * ((w + 1) // 2)
-                send = torch.zeros((per, fsz), dtype=torch.uint8, device=comm_device)
-                if my_recs:
-                    send[:len(my_recs)] = _frames_to_tensor(my_recs, comm_device)
-                gathered = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(gathered, send)
-                all_bytes = [None] * world
-                dist.all_gather_object(all_bytes, (my_bytes, data_dim))
-                dims = [d for _, d in all_bytes if d is not None]
-                data_dim = data_dim or (dims[0] if dims else None)
-                all_bytes = [b for b, _ in all_bytes]
-                all_recs = [_tensor_to_frames(g[:len(items[r::world])], h, w, dev) for r, g in enumerate(gathered)]
-            for r in range(world):
-                for (u, f), b, rc in zip(items[r::world], all_bytes[r], all_recs[r]):
-                    fbytes[u][f], rec[u][f] = b, rc
+            for (u, f), rc in zip(items, shard.exchange_frames(items, my_recs, h, w, dev)):
+                rec[u][f] = rc
+    keys = [(u, f) for u in range(len(units)) for f in names]
+    fbytes = shard.gather_bytes(fbytes, keys)
+    data_dim = shard.agree(data_dim)
     head = hdr.gop_header_bytes(gop_name, idx_rate)
-    blobs = [container.pack_gop(head, [fbytes[u][f] for f in names]) for u in range(len(units))]
+    blobs = [container.pack_gop(head, [fbytes[(u, f)] for f in names]) for u in range(len(units))]
     return blobs, data_dim
 
 
-def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, comm_device=None):
-    """Like FrameCodec.decode_units for ONE GOP structure, with the frames of every dependency level
-    distributed round-robin over the ranks (clips with fewer intra-period units than GPUs: configs[3] on 8
-    GPUs, configs[4]).  Every rank passes the same blobs and returns the same reconstructions; the only
-    exchange is one all_gather of the new 8-bit frames per level (they are the references of the next)."""
+def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, shard=None):
+    """Like FrameCodec.decode_units for ONE GOP structure, frames of every dependency level round-robin over
+    the ranks of the group; every rank returns the same reconstructions."""
     from .codec import frame_index
     from .func_util.GOP_structure import coding_levels, generate_gop_struct
     from .real_life import cat_binary_files as container
-    rank, world = rank_world()
+    device = device if device is not None else (torch.device('cuda', torch.cuda.current_device())
+                                                if torch.cuda.is_available() else torch.device('cpu'))
+    shard = shard or _whole_world_shard(device)
     parsed = [container.unpack_gop(g) for g in gop_blobs]
     gop_name, idx_rate = parsed[0][0], parsed[0][1]
     if any((p[0], p[1]) != (gop_name, idx_rate) for p in parsed):
@@ -185,11 +309,10 @@ def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, co
     names = sorted(gop, key=frame_index)
     h, w = data_dim['x']
     rec = [dict() for _ in gop_blobs]
-    dev = device
     for level in coding_levels(gop):
         for ftype in sorted({gop[f]['type'] for f in level}):
             items = [(u, f) for u in range(len(gop_blobs)) for f in level if gop[f]['type'] == ftype]
-            mine = items[rank::world]
+            mine = shard.mine(items)
             my_recs = []
             for s in range(0, len(mine), frame_codec.max_batch):
                 chunk = mine[s:s + frame_codec.max_batch]
@@ -197,21 +320,11 @@ def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, co
                                                     [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
                                                     [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, data_dim,
                                                     idx_rate, device)
-            if my_recs and dev is None:
-                dev = my_recs[0]['y'].device
-            if world == 1:
-                all_recs = [my_recs]
-            else:
-                cdev = comm_device or dev or torch.device('cpu')
-                per = (len(items) + world - 1) // world
-                fsz = h * w + 2 * ((h + 1) // 2) * ((w + 1) // 2)
-                send = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
-                if my_recs:
-                    send[:len(my_recs)] = _frames_to_tensor(my_recs, cdev)
-                gathered = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(gathered, send)
-                all_recs = [_tensor_to_frames(g[:len(items[r::world])], h, w, dev or cdev) for r, g in enumerate(gathered)]
-            for r in range(world):
-                for (u, f), rc in zip(items[r::world], all_recs[r]):
-                    rec[u][f] = rc
+            for (u, f), rc in zip(items, shard.exchange_frames(items, my_recs, h, w, device)):
+                rec[u][f] = rc
     return [[rec[u][f] for f in names] for u in range(len(gop_blobs))]
+
+
+def _whole_world_shard(device):
+    """all ranks form ONE group (level sharding only): ClipShard of a single unit"""
+    return ClipShard(1, device)

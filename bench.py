@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- encode+decode throughput of the AIVC hot path on MI355X.
 
-One "step" = encode + decode of one intra-period unit (33 frames: I, P, 31 hierarchical B) of
-synthetic 1920x1080 8-bit YUV 4:2:0 video under random-access coding `1_GOP_32` (BASELINE.json
-configs[3], the configuration the metric is quoted on; it fits one GPU).  Units are independent
-(own I frame), so with N GPUs each rank codes its own units (weak scaling, no data-path collective;
-one broadcast of the weights at start).  Inputs are resident in HBM before the timed region.
+One "step" = encode + decode of ONE 128-frame clip of synthetic 1920x1080 8-bit YUV 4:2:0 video under
+random-access coding `1_GOP_32` (BASELINE.json configs[3], the configuration the metric is quoted on; it fits
+one GPU): 4 intra-period units of 33 frames (I, P, 31 hierarchical B) = 132 coded frames, the last 4 being the
+repetition of the last frame that completes the last GOP (src/model_mngt/model_management.py:142-153).
+`value` counts the 128 REQUESTED frames over wall time, as the reference prints it (real_life/encode.py:165);
+coded frames per second are reported next to it.  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline      dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic FLOPs per launch / average
-                launch duration, measured with HIP events on the launch stream during an extra,
-                untimed, instrumented step.
-  cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded sample.
+N GPUs (one process per GPU, torch.distributed over RCCL):
+  --scaling strong (default for N > 1): the SAME clip on all GPUs -- units over min(N, 4) groups, temporal-layer
+      sharding inside a group (aivc_amd/parallel.py: ClipShard); per level one all_gather of 8-bit frames inside
+      the group, per clip the gather of the bitstream; bytes asserted identical to a single-rank encode.
+  --scaling weak: every rank its own clip, no data-path collective at all; also measured in the default run
+      and reported as `weak_scaling` (the replica figure).
+One broadcast of the weights at start in both modes.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
+  roofline      dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic FLOPs per launch / average launch
+                duration, measured with HIP events on the launch stream during an extra, untimed, instrumented
+                step; `hbm_stages`: achieved GB/s of the memory-bound stages against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (a port, oracle/) timed on this box's host cores on a bounded sample (all cores
+                and one core, encode and decode separately); the GPU codes the same full-size frames with the
+                same default-width model and the bytes / reconstructions are asserted equal (`parity_checked`).
 """
 import argparse
 import json
@@ -25,6 +36,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0         # same guide: HBM3E 8 TB/s (spec; 6.3 TB/s is the measured copy ceiling)
 _TILES = {0: '128x128', 1: '64x64', 2: '256x64', 3: '128x32', 4: '256x128', 5: '64x128'}
 _MODES = {0: 'conv', 1: 'tconv', 2: 'gdn'}
 
@@ -76,9 +88,22 @@ def gpu_synthetic_unit(width, height, n_frames, t0, device, seed):
     return out
 
 
-def cpu_baseline(width, height, model):
-    """Oracle (CPU port) encode+decode of an I + P pair; falls back to a quarter-size frame when a
-    probe says the full-size sample would exceed ~40 s."""
+def _omp_threads(n):
+    """set the thread count of the oracle's OpenMP regions (libgomp is already in the process)"""
+    import ctypes
+    try:
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
+def cpu_baseline(width, height, model, fc, dev):
+    """The CPU oracle (a port: the reference needs its absent model sources, weights and torchac to run) on an
+    I + P + B triple (`1_GOP_2`), encode and decode timed separately:
+      * all host threads, full-size frames (reduced to half size when a probe predicts > 150 s);
+      * one thread, a 1/64-area crop of the same pattern, scaled by the pixel ratio.
+    The GPU codes the SAME full-size frames with the same model: bytes and reconstructions must be equal."""
     import numpy as np
     from aivc_amd import synth
     from oracle import codec as ocodec
@@ -90,26 +115,50 @@ def cpu_baseline(width, height, model):
     # probe: one 3x3 128->128 conv on a 135x240 map (9.6 GFLOP)
     x = np.random.default_rng(0).standard_normal((1, 135, 240, 128), dtype=np.float32)
     w = np.random.default_rng(1).standard_normal((128, 3, 3, 128), dtype=np.float32) * 0.03
+    orc.conv2d(x[:, :16], w, None, pad=1)
     t = time.time()
     orc.conv2d(x, w, None, pad=1)
     gflops = 9.56 / max(time.time() - t, 1e-6)
-    est_full = 3200.0 / gflops  # ~3.2 TFLOP for I + P at 1080p with the default widths
-    scale = 1
-    w_s, h_s = width, height
-    if est_full > 40.0:
-        scale, w_s, h_s = 4, width // 2, height // 2
-    frames = synth.synthetic_video(w_s, h_s, 2, seed=11)
-    t = time.time()
-    blob, _ = ocodec.encode_video(spec, frames, 'LDP_1')
-    ocodec.decode_video(spec, blob)
-    dt = time.time() - t
-    fps = 2.0 / dt / scale
-    sample = ('oracle encode+decode of 2 frames (I+P, LDP_1) at %dx%d in %.1f s on %d threads'
-              % (w_s, h_s, dt, cores))
-    if scale != 1:
-        sample += '; fps divided by %d (pixel ratio to %dx%d)' % (scale, width, height)
-    return {'value': round(fps, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'sample': sample,
-            'probe_conv_gflops': round(gflops, 1)}
+    est_full = 6200.0 / gflops  # ~6.2 TFLOP for I + P + B encode + decode at 1080p with the default widths
+    w_s, h_s = (width, height) if est_full <= 150.0 else (width // 2, height // 2)
+    scale = (width * height) / float(w_s * h_s)
+    frames = synth.synthetic_video(w_s, h_s, 3, seed=11)
+    t0 = time.time()
+    blob, recs = ocodec.encode_video(spec, frames, '1_GOP_2')
+    t1 = time.time()
+    dec = ocodec.decode_video(spec, blob)
+    t2 = time.time()
+    enc_s, dec_s = t1 - t0, t2 - t1
+    # ---- the same frames through the HIP product path: default-width parity, checked in the driver-run bench
+    with torch.no_grad():
+        g_enc = fc.encode_video(synth.to_device_frames(frames, dev), '1_GOP_2')
+        g_blob = fc.assemble_video(g_enc)
+        g_dec, _, _, _ = fc.decode_video(g_blob, dev)
+    parity = g_blob == blob and all(np.array_equal(g[k][0].cpu().numpy(), r[k]) and np.array_equal(r[k], d[k])
+                                    for g, r, d in zip(g_dec, recs, dec) for k in 'yuv')
+    if not parity:
+        raise SystemExit('bench.py: HIP bitstream / reconstruction differs from the CPU oracle at default widths')
+    out = {'value': round(3.0 / (enc_s + dec_s) / scale, 5), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+           'encode_fps': round(3.0 / enc_s / scale, 5), 'decode_fps': round(3.0 / dec_s / scale, 5),
+           'sample': 'oracle (OpenMP + fmaf) on 3 frames I+P+B (1_GOP_2) at %dx%d: encode %.1f s, decode %.1f s on %d threads%s'
+                     % (w_s, h_s, enc_s, dec_s, cores, '' if scale == 1 else '; fps divided by %g (pixel ratio to %dx%d)' % (scale, width, height)),
+           'probe_conv_gflops': round(gflops, 1), 'parity_checked': True, 'parity_bytes': len(blob)}
+    # ---- one core
+    if _omp_threads(1):
+        w1, h1 = max(64, width // 8 // 16 * 16), max(48, height // 8 // 8 * 8)
+        f1 = synth.synthetic_video(w1, h1, 3, seed=11)
+        t0 = time.time()
+        b1, _ = ocodec.encode_video(spec, f1, '1_GOP_2')
+        t1 = time.time()
+        ocodec.decode_video(spec, b1)
+        t2 = time.time()
+        s1 = (width * height) / float(w1 * h1)
+        out['one_core'] = {'value': round(3.0 / (t2 - t0) / s1, 6), 'encode_fps': round(3.0 / (t1 - t0) / s1, 6),
+                           'decode_fps': round(3.0 / (t2 - t1) / s1, 6), 'cores': 1,
+                           'sample': 'same triple at %dx%d on 1 thread: encode %.1f s, decode %.1f s; fps divided by %.1f (pixel ratio)'
+                                     % (w1, h1, t1 - t0, t2 - t1, s1)}
+        _omp_threads(cores)
+    return out
 
 
 def main():
@@ -120,7 +169,9 @@ def main():
     ap.add_argument('--width', type=int, default=1920)
     ap.add_argument('--height', type=int, default=1080)
     ap.add_argument('--gop', type=str, default='1_GOP_32')
-    ap.add_argument('--units', type=int, default=4, help='intra-period units per step per GPU (4 x 33 = the 128-frame clip of BASELINE configs[3])')
+    ap.add_argument('--frames', type=int, default=128, help='requested frames of the clip (BASELINE configs[3]: 128)')
+    ap.add_argument('--scaling', choices=('auto', 'strong', 'weak'), default=os.environ.get('AIVC_BENCH_SCALING', 'auto'),
+                    help='auto = strong (one clip over all GPUs) when N > 1')
     ap.add_argument('--max-batch', type=int, default=8)
     ap.add_argument('--entropy-streams', type=int, default=4, help='decoder: concurrent range-coder chains')
     ap.add_argument('--entropy-lookahead', type=int, default=2, help='decoder: dependency levels of entropy decoding issued ahead')
@@ -140,67 +191,108 @@ def main():
     use_dist = world > 1 or bool(os.environ.get('AIVC_FORCE_DIST'))  # (the env var exercises the RCCL path on 1 GPU)
     if use_dist:
         dist.init_process_group('nccl', device_id=dev)
+    strong = args.scaling == 'strong' or (args.scaling == 'auto')
 
-    from aivc_amd import ops, synth
+    from aivc_amd import ops, parallel, synth
     from aivc_amd.func_util.GOP_structure import generate_gop_struct
     from aivc_amd.models import arch
-    from aivc_amd.parallel import broadcast_model
     widths = arch.TINY_WIDTHS if args.tiny else arch.DEFAULT_WIDTHS
     seed = 1234
     model = synth.make_model(widths, seed=seed, device=dev)
-    synth.calibrate_operating_point(model, dev)
+    active_y = (6, 12)
+    synth.calibrate_operating_point(model, dev, active_y=active_y)
     if use_dist:
-        broadcast_model(model)  # the one collective: weights over RCCL/xGMI
+        parallel.broadcast_model(model)  # the one collective on the weights: RCCL over xGMI
     from aivc_amd.codec import FrameCodec
     fc = FrameCodec(model, max_batch=args.max_batch, entropy_streams=args.entropy_streams,
                     entropy_lookahead=args.entropy_lookahead)
     unit = len(generate_gop_struct(args.gop))
-    per_step = unit * args.units
-    n_total = args.warmup + args.steps + 1
-    # unit u of this rank's share = global unit (rank + u * world)
-    clips = [gpu_synthetic_unit(args.width, args.height, per_step, (rank + i * world) * per_step, dev, 666 + rank + i * world)
-             for i in range(n_total)]
-    torch.cuda.synchronize()
+    n_units = -(-args.frames // unit)
+    coded = n_units * unit
 
+    def make_clip(index):
+        """clip `index`: args.frames distinct frames, the last unit completed by repeating the last frame"""
+        fr = gpu_synthetic_unit(args.width, args.height, args.frames, index * args.frames, dev, 666 + index)
+        fr = fr + [fr[-1]] * (coded - args.frames)
+        return [fr[u * unit:(u + 1) * unit] for u in range(n_units)]
+
+    n_total = args.warmup + args.steps + 1
+    shard = parallel.ClipShard(n_units, dev) if strong else None
+    # strong: every rank holds the same clips; weak: rank r codes clips r, r + world, ...
+    clips = [make_clip(i if strong else rank + i * world) for i in range(n_total)]
+    torch.cuda.synchronize()
     stats = {'enc_s': 0.0, 'dec_s': 0.0, 'bytes': 0}
 
-    def step(i, timed=False):
+    def step(clip, timed=False, sh=None):
+        """encode then decode one clip -> (gop records, data_dim, {unit: reconstructions of the encoder}, decoded)"""
         with torch.no_grad():
             t0 = time.time()
-            enc = fc.encode_video(clips[i], args.gop)
-            blob = fc.assemble_video(enc)
+            if sh is not None:
+                blobs, dd = parallel.encode_clip(fc, clip, args.gop, shard=sh)
+                enc_recs = None
+            else:
+                blobs, enc_recs, dd = fc.encode_units(clip, args.gop)
             if timed:
                 torch.cuda.synchronize()
                 t1 = time.time()
-            dec, _, _, _ = fc.decode_video(blob, dev)
+            if sh is not None:
+                dec = parallel.decode_clip(fc, blobs, dd, dev, shard=sh)
+            else:
+                dec = dict(enumerate(fc.decode_units(blobs, dd, dev)))
             if timed:
                 torch.cuda.synchronize()
                 stats['enc_s'] += t1 - t0
                 stats['dec_s'] += time.time() - t1
-                stats['bytes'] += len(blob)
-        return enc, dec
-
-    closed_loop = True
-    for i in range(args.warmup):
-        enc, dec = step(i)
-        rec = [r for g in enc['recs'] for r in g][:len(dec)]
-        closed_loop &= all(torch.equal(d[k], e[k]) for d, e in zip(dec, rec) for k in 'yuv')
+                stats['bytes'] += sum(len(b) for b in blobs)
+        return blobs, dd, enc_recs, dec
 
     def barrier():
         if use_dist:
             dist.barrier()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i, timed=True)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.time() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    def timed_run(sh, first):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for i in range(first, first + args.steps):
+            step(clips[i], timed=True, sh=sh)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.time() - t0
+        if use_dist:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    # ---- warm-up; closed loop (decoder == encoder reconstruction) and, for the sharded path, bytes == single rank
+    closed_loop, bytes_equal = True, None
+    for i in range(args.warmup):
+        blobs, dd, enc_recs, dec = step(clips[i], sh=shard)
+        if enc_recs is None:  # sharded: this rank's own single-process encode of the same clip is the reference
+            with torch.no_grad():
+                ref_blobs, enc_recs, _ = fc.encode_units(clips[i], args.gop)
+            bytes_equal = (bytes_equal is not False) and blobs == ref_blobs
+        for u, frs in dec.items():
+            closed_loop &= all(torch.equal(d[k], e[k]) for d, e in zip(frs, enc_recs[u]) for k in 'yuv')
+    if bytes_equal is False:
+        raise SystemExit('bench.py: sharded bitstream differs from the single-rank bitstream')
+    elapsed = timed_run(shard, args.warmup)
+    main_stats = dict(stats)
+
+    # ---- the other scaling mode, reported next to the headline (N > 1 only: at N = 1 they coincide)
+    other = None
+    if world > 1 and args.scaling == 'auto':
+        weak_clips = [make_clip(rank + i * world) for i in range(args.steps)]
+        clips_backup, clips = clips, weak_clips
+        stats.update(enc_s=0.0, dec_s=0.0, bytes=0)
+        el_w = timed_run(None, 0)
+        clips = clips_backup
+        other = {'scaling': 'weak', 'value': round(world * args.steps * args.frames / el_w, 4), 'unit': 'frames/s',
+                 'ms_per_step': round(el_w / args.steps * 1e3, 2),
+                 'note': 'every rank its own %d-frame clip (replicas, no data-path collective)' % args.frames}
+        del weak_clips
+    stats = main_stats
 
     # quality of what was coded (outside the timed region; on-device CLIC metrics, aivc_amd/clic21): first
     # intra-period unit of the first timed clip.  With the synthetic random-init weights the figures say nothing
@@ -209,24 +301,25 @@ def main():
     quality = None
     if rank == 0 and not os.environ.get('AIVC_NO_QUALITY'):
         from aivc_amd.clic21.metrics import evaluate
+        src_unit = clips[args.warmup][0]
         with torch.no_grad():
-            q_enc = fc.encode_video(clips[args.warmup][:unit], args.gop)
-            q_blob = fc.assemble_video(q_enc)
-            q_dec, _, _, _ = fc.decode_video(q_blob, dev)
+            q_blobs, _, q_dd = fc.encode_units([src_unit], args.gop)
+            q_dec = fc.decode_units(q_blobs, q_dd, dev)[0]
         target, submit = {}, {}
-        for i, (src, d) in enumerate(zip(clips[args.warmup][:unit], q_dec)):
+        for i, (src, d) in enumerate(zip(src_unit, q_dec)):
             for k in 'yuv':
                 target['%d_%s' % (i, k)] = src[k]
                 submit['%d_%s' % (i, k)] = d[k]
         r = evaluate(submit, target)
         quality = {'frames': unit, 'psnr_db': round(float(r['PSNR']), 4), 'ms_ssim': round(float(r['MSSSIM']), 6),
-                   'bpp': round(len(q_blob) * 8.0 / (unit * args.width * args.height), 5),
+                   'bpp': round(len(q_blobs[0]) * 8.0 / (unit * args.width * args.height), 5),
                    'note': 'synthetic random-init weights: not a rate-distortion result'}
 
     roofline = None
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
-        step(n_total - 1)
+        ops.PROFILE_HBM = []
+        step(clips[n_total - 1])  # one single-rank step, instrumented
         torch.cuda.synchronize()
         per = {}
         shapes = {}
@@ -237,6 +330,12 @@ def main():
                 d[0] += 1
                 d[1] += flops
                 d[2] += sec_
+        hbm = {}
+        for name, nbytes, e0, e1 in ops.PROFILE_HBM:
+            d = hbm.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += nbytes
+            d[2] += e0.elapsed_time(e1) * 1e-3
         if os.environ.get('AIVC_LAYER_TABLE'):  # tuning aid: per-layer-shape time of one step, on stderr
             for key, d in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
                 v, mode, k, st, ci, co, nb, hh, ww, g = key
@@ -244,24 +343,25 @@ def main():
                     d[2] * 1e3, d[0], d[1] / d[2] / 1e12, VARIANT_NAMES.get(v, str(v)), mode, k, st, ci, co,
                     '+gdn' if g else '', nb, hh, ww))
         ops.PROFILE = None
+        ops.PROFILE_HBM = None
         mf = {v: d for v, d in per.items() if v >= 100}
         if mf:
             dom = max(mf, key=lambda v: mf[v][2])
             cnt, fl, sec = mf[dom]
             all_fl = sum(d[1] for d in mf.values())
             all_sec = sum(d[2] for d in mf.values())
-            traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_probe.json')
+            traffic, traffic_note, counters = None, None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
-                    traffic = pj['traffic_bytes_per_launch']
-                    traffic_note = ('HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on '
-                                    'the probe shape (%s): %d B vs %d B algorithmic' % (pj['probe'], traffic,
-                                                                                         pj['algorithmic_bytes_per_launch']))
+                    traffic = pj.get('traffic_bytes_per_launch')
+                    traffic_note = pj.get('note')
+                    counters = pj.get('sq_counters')
             roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
                         'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_note': traffic_note,
+                        'mfma_counters': counters,
                         'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 2),
                         'gflop_per_launch': round(fl / cnt / 1e9, 3),
                         'all_mfma_conv': {'achieved': round(all_fl / all_sec / 1e12, 2),
@@ -269,34 +369,55 @@ def main():
                                           'tflop_per_step': round(all_fl / 1e12, 3),
                                           'kernel_s_per_step': round(all_sec, 4)},
                         'per_variant': {VARIANT_NAMES.get(v, str(v)): {'launches': d[0], 'tflops': round(d[1] / d[2] / 1e12, 2),
+                                                                       'frac': round(d[1] / d[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                                                        'ms_total': round(d[2] * 1e3, 2)}
-                                        for v, d in sorted(per.items())}}
+                                        for v, d in sorted(per.items())},
+                        'hbm_stages': {name: {'bound': 'hbm', 'launches': d[0], 'achieved': round(d[1] / d[2] / 1e9, 1),
+                                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(d[1] / d[2] / 1e9 / HBM_PEAK_GBS, 4),
+                                              'algorithmic_mb_per_launch': round(d[1] / d[0] / 1e6, 2),
+                                              'ms_total': round(d[2] * 1e3, 2)}
+                                       for name, d in sorted(hbm.items())}}
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.width, args.height, model)
+        cpu = cpu_baseline(args.width, args.height, model, fc, dev)
 
     if rank == 0:
-        frames = world * args.steps * per_step
+        scaling = 'strong' if strong else 'weak'
+        clips_done = args.steps * (1 if strong else world)
+        g = shard.G if shard is not None else 1
+        r_ = shard.R if shard is not None else 1
         out = {
             'metric': 'encode+decode fps @1080p YUV420 (RA GOP32)',
-            'value': round(frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: %d-frame clip (%d intra-period units of %d frames) encoded + '
-                                   'decoded per step per GPU; synthetic random-init stand-in for model ms_ssim-4 '
-                                   '(widths %s); units sharded across GPUs' % (args.width, args.height, args.gop, per_step, args.units, unit, widths),
-                       'frames_per_step': per_step, 'units_per_step': args.units, 'parallelism': 'unit-sharded x%d' % world},
-            'encode_fps_rank0': round(args.steps * per_step / stats['enc_s'], 3),
-            'decode_fps_rank0': round(args.steps * per_step / stats['dec_s'], 3),
-            'bytes_per_frame': round(stats['bytes'] / (args.steps * per_step), 1),
-            'closed_loop_ok': bool(closed_loop), 'quality': quality,
+            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: one %d-frame clip = %d intra-period units of %d frames '
+                                   '(%d coded frames, the last %d repeat the last frame) encoded + decoded per step; synthetic '
+                                   'random-init stand-in for model ms_ssim-4 (widths %s), last analysis conv calibrated so that '
+                                   '%d (MOFNet) / %d (CodecNet) of the %d y feature maps are non-zero (low-rate operating point); %s'
+                                   % (args.width, args.height, args.gop, args.frames, n_units, unit, coded, coded - args.frames, widths,
+                                      active_y[0], active_y[1], widths['c_y'],
+                                      ('the clip sharded over %d GPUs: %d unit groups x %d ranks of temporal-layer sharding' % (world, g, r_))
+                                      if strong else 'one clip per GPU (replicas)'),
+                       'requested_frames_per_step': args.frames, 'coded_frames_per_step': coded, 'units_per_step': n_units,
+                       'nonzero_y_maps': {'mofnet': active_y[0], 'codecnet': active_y[1], 'of': widths['c_y']},
+                       'parallelism': ('unit-groups x%d, level-sharded x%d' % (g, r_)) if strong else 'replicas x%d' % world},
+            'coded_frames_per_s': round(clips_done * coded / elapsed, 4),
+            'encode_fps_rank0': round(args.steps * args.frames / stats['enc_s'], 3),
+            'decode_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),
+            'bytes_per_frame': round(stats['bytes'] / (args.steps * coded), 1),
+            'closed_loop_ok': bool(closed_loop), 'bytes_equal_single_rank': bytes_equal,
+            'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if other is not None:
+            out['weak_scaling'] = other
         if args.tiny:
             out['invalid'] = 'tiny debug model'
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()  # the other ranks wait for rank 0's instrumented step before tearing RCCL down
         dist.destroy_process_group()
 
 

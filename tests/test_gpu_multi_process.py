@@ -1,0 +1,85 @@
+"""Strong-scaling path (aivc_amd/parallel.py: ClipShard, encode_clip / decode_clip) with the HIP codec and REAL
+process boundaries on the one GPU of the test box: two processes share cuda:0 for the kernels and talk over gloo
+(host tensors) -- RCCL refuses two ranks on one device.  What this covers that the CPU gloo tests cannot: the
+level-sharded FrameCodec.encode_units / decode_units (side streams, deferred flags, per-level exchange) produce
+the bytes and frames of a single process."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_units, gop, w=80, h=48):
+    from aivc_amd import synth
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    from aivc_amd.models import arch
+    dev = torch.device('cuda:0')
+    model = synth.make_model(arch.TINY_WIDTHS, seed=77, device=dev)
+    unit = len(generate_gop_struct(gop))
+    frames = synth.to_device_frames(synth.synthetic_video(w, h, unit * n_units, seed=4), dev)
+    units = [frames[u * unit:(u + 1) * unit] for u in range(n_units)]
+    return model, units, dev
+
+
+def _worker(rank, world, port, q, n_units, gop):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from aivc_amd import parallel
+    model, units, dev = _setup(n_units, gop)
+    parallel.broadcast_model(model)
+    fc = model.frame_codec()
+    shard = parallel.ClipShard(n_units, dev)
+    with torch.no_grad():
+        blobs, dd = parallel.encode_clip(fc, units, gop, shard=shard)
+        recs = parallel.decode_clip(fc, blobs, dd, dev, shard=shard)
+    torch.cuda.synchronize()
+    digest = {u: [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).cpu().numpy()) for fr in frs] for u, frs in recs.items()}
+    q.put((rank, blobs, (shard.G, shard.R), digest))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_units,gop,layout', [(1, '1_GOP_8', (1, 2)), (2, '1_GOP_4', (2, 1)), (1, '2_GOP_4', (1, 2))])
+def test_two_processes_one_gpu_match_single_process(n_units, gop, layout, cuda):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, n_units, gop)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] == res[1][2] == layout
+    assert res[0][1] == res[1][1]
+    model, units, dev = _setup(n_units, gop)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        ref_blobs, ref_recs, dd = fc.encode_units(units, gop)
+        ref_dec = fc.decode_units(ref_blobs, dd, dev)
+    assert res[0][1] == ref_blobs
+    for r in res:
+        for u, got in r[3].items():
+            want = [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).cpu().numpy()) for fr in ref_dec[u]]
+            assert got == want
+            enc = [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).cpu().numpy()) for fr in ref_recs[u]]
+            assert got == enc  # decoder == encoder reconstruction
+
+
+def test_single_rank_clip_shard_is_the_plain_path(cuda):
+    from aivc_amd import parallel
+    model, units, dev = _setup(2, 'LDP_2')
+    fc = model.frame_codec()
+    with torch.no_grad():
+        blobs, dd = parallel.encode_clip(fc, units, 'LDP_2')
+        ref_blobs, _, ref_dd = fc.encode_units(units, 'LDP_2')
+        recs = parallel.decode_clip(fc, blobs, dd, dev)
+    assert blobs == ref_blobs and dd == ref_dd and sorted(recs) == [0, 1]

@@ -114,6 +114,15 @@ class OracleFrameCodec:
             secs.append(fb)
         return {'sections': secs, 'rec': recs, 'data_dim': dict(dd, x_uv=None)}
 
+    def encode_units(self, units, gop_name, idx_rate=0., shard=None):
+        from aivc_amd import parallel
+        blobs, dd = parallel.encode_units_level_sharded(self, units, gop_name, idx_rate, shard=shard)
+        return blobs, None, dd
+
+    def decode_units(self, gop_blobs, data_dim, device=None, shard=None):
+        from aivc_amd import parallel
+        return parallel.decode_units_level_sharded(self, gop_blobs, data_dim, device or torch.device('cpu'), shard=shard)
+
     def decode_batch(self, frames_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., device=None):
         from oracle import codec as oc
 
@@ -181,7 +190,7 @@ def _worker_levels_decode(rank, world, port, q):
     gops = oc.split_lp(blob, 18, 2)
     dd = {'x': (32, 48), 'y': tuple(int.from_bytes(blob[i:i + 2], 'big') for i in (4, 6)),
           'z': tuple(int.from_bytes(blob[i:i + 2], 'big') for i in (8, 10))}
-    recs = parallel.decode_units_level_sharded(OracleFrameCodec(spec), gops, dd, comm_device=torch.device('cpu'))
+    recs = parallel.decode_units_level_sharded(OracleFrameCodec(spec), gops, dd, device=torch.device('cpu'))
     digest = [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).numpy()) for unit in recs for fr in unit]
     q.put((rank, digest))
     dist.destroy_process_group()
@@ -211,3 +220,54 @@ def test_temporal_level_sharded_decode_matches_single_process(oracle):
     frames = oc.decode_video(spec, blob)
     want = [bytes(np.concatenate([np.asarray(fr[k]).reshape(-1) for k in 'yuv'])) for fr in frames]
     assert res[0][1] == want
+
+
+# ---- one clip over 4 ranks: 2 unit groups x 2 ranks of level sharding (the layout of BASELINE configs[3] on 8 GPUs)
+def _worker_clip(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import aivc_amd.real_life.bitstream as bs
+    bs.finalize_frames = lambda secs: list(secs)  # the oracle codec already returns frame bytes
+    from aivc_amd import parallel, synth
+    from aivc_amd.models import arch
+    from oracle import spec as ospec
+    model = synth.make_model(arch.TINY_WIDTHS, seed=100)
+    frames = synth.synthetic_video(48, 32, 10, seed=2)
+    units = [[{k: torch.from_numpy(f[k]).unsqueeze(0) for k in 'yuv'} for f in frames[u * 5:u * 5 + 5]] for u in range(2)]
+    codec = OracleFrameCodec(ospec.export_model(model))
+    shard = parallel.ClipShard(len(units), torch.device('cpu'))
+    blobs, dd = parallel.encode_clip(codec, units, '1_GOP_4', shard=shard)
+    recs = parallel.decode_clip(codec, blobs, dd, torch.device('cpu'), shard=shard)
+    digest = {u: [bytes(torch.cat([fr[k].reshape(-1) for k in 'yuv']).numpy()) for fr in frs] for u, frs in recs.items()}
+    q.put((rank, blobs, (dd['x'], dd['y'], dd['z']), (shard.G, shard.R, shard.group_id, shard.local, shard.units), digest))
+    dist.destroy_process_group()
+
+
+def test_clip_over_unit_groups_and_levels_matches_single_process(oracle):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_clip, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [(2, 2, 0, 0, [0]), (2, 2, 0, 1, [0]), (2, 2, 1, 0, [1]), (2, 2, 1, 1, [1])]
+    assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)  # every rank holds the whole bitstream
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from oracle import codec as oc
+    from oracle import spec as ospec
+    spec = ospec.export_model(synth.make_model(arch.TINY_WIDTHS, seed=100))
+    ref, _ = oc.encode_video(spec, synth.synthetic_video(48, 32, 10, seed=2), '1_GOP_4')
+    assert oc.split_lp(ref, 18, 2) == res[0][1]
+    frames = oc.decode_video(spec, ref)
+    want = [bytes(np.concatenate([np.asarray(fr[k]).reshape(-1) for k in 'yuv'])) for fr in frames]
+    for r in res:
+        (u, got), = r[4].items()  # each rank holds the frames of its group's unit
+        assert got == want[5 * u:5 * u + 5]
