@@ -122,14 +122,26 @@ def debug_dir(bitstream_path):
 
 
 def plane_md5(plane):
+    """Digest flag_bitstream_debug compares per plane.  The reference hashes the PNG FILE it saved for the plane
+    (save_yuv_separately -> to_pil_image(mode='L').save, src/func_util/img_processing.py:290-302; compare at
+    src/real_life/decode.py:304-326): the same file is produced here in memory with PIL, so the .md5 files
+    interoperate with a reference decoder / encoder running the same Pillow + zlib (the PNG byte stream depends
+    on them; pinned by tests/golden/decoder_*.npz `pngmd5_*`).  Without PIL: digest of the raw 8-bit plane."""
     import hashlib
     a = plane.cpu().numpy() if isinstance(plane, torch.Tensor) else np.asarray(plane)
-    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+    a = np.ascontiguousarray(a.reshape(a.shape[-2], a.shape[-1]))
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return hashlib.md5(a.tobytes()).hexdigest()
+    buf = io.BytesIO()
+    Image.fromarray(a, 'L').save(buf, format='PNG')
+    return hashlib.md5(buf.getvalue()).hexdigest()
 
 
 def write_debug_md5(frames, first, directory):
-    """encoder side of flag_bitstream_debug: '<idx>_<c>.md5' per reconstructed plane.  The reference hashes the PNG
-    files it writes (src/real_life/decode.py:304-326); there are no PNGs here, the digest is of the 8-bit plane."""
+    """encoder side of flag_bitstream_debug: '<idx>_<c>.md5' per reconstructed plane (see plane_md5)."""
     os.makedirs(directory, exist_ok=True)
     for i, fr in enumerate(frames):
         for c in 'yuv':

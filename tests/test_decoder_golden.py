@@ -264,3 +264,16 @@ def test_hip_arithmetic_coder_path_api(case, md5, cuda, golden, tmp_path, capsys
             assert torch.equal(q, lat(name, 'q'))
     out = capsys.readouterr().out
     assert 'Ko!' not in out and '[Error]' not in out and 'Ok! Entropy coding is lossless' in out
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_debug_plane_digest_is_the_reference_png_md5(case, golden):
+    """flag_bitstream_debug (src/real_life/decode.py:304-326) compares md5 sums of the PNG FILES of the decoded
+    planes: the product's in-memory PNG gives the digest the reference computed for the file it wrote."""
+    pytest.importorskip('PIL')
+    from aivc_amd.real_life.decode import plane_md5
+    g = golden(case)
+    m = _meta(g)
+    for i in range(m['n']):
+        for c in 'yuv':
+            assert plane_md5(np.asarray(g['dec_%d_%s' % (m['first'] + i, c)])) == str(g['pngmd5_%d_%s' % (m['first'] + i, c)])

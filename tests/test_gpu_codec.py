@@ -382,3 +382,48 @@ def test_bitstream_debug_flag(cuda, tmp_path, capsys):
                       'flag_bitstream_debug': True})
     out = capsys.readouterr().out
     assert out.count('Incorrect reconstruction!') == 1 and out.count('Identical reconstruction!') == 3 * n - 1
+
+
+def test_full_module_pickle_load_model_round_trip(cuda, tmp_path):
+    """src/model_mngt/model_management.py:341-361: a reference .pt is torch.save(<whole FullNet>) whose classes are
+    named `models.*` / `layers.*`; `load_model(prefix, on_cpu)` unpickles it from the working directory and attaches
+    the arithmetic coders.  Written here with the reference's module names, loaded back through the aliased
+    `model_mngt.model_management.load_model`, moved to the GPU: same bitstream, same frames as the original."""
+    import importlib
+    import aivc_amd
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    model = synth.make_model(arch.TINY_WIDTHS, seed=21)
+    for net in (model.codec_net.codec_net, model.mode_net.mode_net):
+        net.ac = None  # not pickled upstream either
+    aivc_amd.install_aliases()
+    classes = {type(m) for m in model.modules() if type(m).__module__.startswith('aivc_amd.')}
+    saved = {c: c.__module__ for c in classes}
+    try:
+        for c in classes:
+            c.__module__ = c.__module__[len('aivc_amd.'):]
+        torch.save(model, str(tmp_path / '0_model.pt'))
+    finally:
+        for c, m in saved.items():
+            c.__module__ = m
+    raw = (tmp_path / '0_model.pt').read_bytes()
+    assert b'models.full_net' in raw and b'aivc_amd.' not in raw
+    mm = importlib.import_module('model_mngt.model_management')  # the reference's import path
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        loaded = mm.load_model(prefix='0_', on_cpu=True)
+    finally:
+        os.chdir(cwd)
+    assert loaded.codec_net.codec_net.ac is not None and loaded.mode_net.mode_net.ac is not None
+    loaded = loaded.to(cuda).eval()
+    orig = synth.make_model(arch.TINY_WIDTHS, seed=21, device=cuda)
+    frames = synth.to_device_frames(synth.synthetic_video(64, 48, 5, seed=8), cuda)
+    with torch.no_grad():
+        a, b = orig.frame_codec(), loaded.frame_codec()
+        blob_a = a.assemble_video(a.encode_video(frames, '1_GOP_4'))
+        blob_b = b.assemble_video(b.encode_video(frames, '1_GOP_4'))
+        assert blob_a == blob_b
+        dec_a, _, _, _ = a.decode_video(blob_a, cuda)
+        dec_b, _, _, _ = b.decode_video(blob_a, cuda)
+    assert all(torch.equal(x[k], y[k]) for x, y in zip(dec_a, dec_b) for k in 'yuv')

@@ -344,9 +344,13 @@ def run_case(model, frames, gop_name, idx_rate, first):
             odir = os.path.join(td, 'dec') + '/'
             TORCHAC_LOG.clear()
             decode_one_video({'decoder': decoder, 'bitstream_path': vpath, 'device': 'cpu', 'out_dir': odir})
+            from real_life.check_md5sum import compute_md5sum
             for i in range(len(frames)):
                 for c in 'yuv':
-                    fix['dec_%d_%s' % (first + i, c)] = np.asarray(Image.open(odir + '%d_%s.png' % (first + i, c)))
+                    png = odir + '%d_%s.png' % (first + i, c)
+                    fix['dec_%d_%s' % (first + i, c)] = np.asarray(Image.open(png))
+                    # what flag_bitstream_debug compares (decode.py:304-326): the md5 of the PNG file itself
+                    fix['pngmd5_%d_%s' % (first + i, c)] = np.array(compute_md5sum({'in_file': png}))
         finally:
             os.chdir(cwd)
     for idx, lat in lats.items():
