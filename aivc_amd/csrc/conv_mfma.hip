@@ -151,24 +151,39 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     b_off[j] = TCONV ? (uint32_t)coc * (uint32_t)(ks * ks * Cin) + (uint32_t)((u % OCT) * 8)
                      : (uint32_t)coc * (uint32_t)K + (uint32_t)((u % OCT) * 8);
   }
+  // The element offset of the unit's input pixel only changes when the K-tile enters a new kernel tap (every
+  // c_in / 32 tiles): it is kept in a register and recomputed behind a wave-uniform branch, every other tile
+  // costs one add per unit (instruction count is what the matrix pipe pays for, see the header).
+  uint32_t a_pix[UA];
+  bool a_in[UA];
+#pragma unroll
+  for (int j = 0; j < UA; ++j) {
+    a_pix[j] = 0;
+    a_in[j] = true;
+  }
   auto load_tile_fast = [&](int kt) {
     const int kbase = kt * BK;
     int ty, tx, ci0;
     tap_of(kbase, ty, tx, ci0);  // wave-uniform
-    const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
+    if (ci0 == 0) {
+      const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
+#pragma unroll
+      for (int j = 0; j < UA; ++j) {
+        int iy = a_by[j] + (TCONV ? dyt : ty), ix = a_bx[j] + (TCONV ? dxt : tx);
+        if (TCONV) a_in[j] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        iy = max(min(iy, H - 1), 0);
+        ix = max(min(ix, W - 1), 0);
+        a_pix[j] = (a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(((tid + 256 * j) % OCT) * 8);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < UA; ++j) {
-      int iy = a_by[j] + (TCONV ? dyt : ty), ix = a_bx[j] + (TCONV ? dxt : tx);
-      bool ok = true;
-      if (TCONV) ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-      iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
-      ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
-      const float *src = p.x + ((a_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)(ci0 + ((tid + 256 * j) % OCT) * 8));
+      const float *src = p.x + (a_pix[j] + (uint32_t)ci0);
       float4 v0 = *reinterpret_cast<const float4 *>(src);
       float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
       if (TCONV) {  // select, not multiply by 0/1: avoids NaN * 0
-        v0 = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
-        v1 = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+        v0 = a_in[j] ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+        v1 = a_in[j] ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (GDN) {
         v0.x *= v0.x; v0.y *= v0.y; v0.z *= v0.z; v0.w *= v0.w;
@@ -676,7 +691,9 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   //   fused GDN, c_out = 128 -> 128x128, or 64x128 for the short reductions of a transposed 3x3
   //   otherwise score the candidates by efficiency class x block-count balance
   if (co <= 32) return 3;
-  if (co <= 64) return 1;
+  // c_out = 64: 256x64 (four waves stacked along M, 4 accumulators each) once there are >= ~1000 such tiles and
+  // the reduction is long; else the small tile (r02 sweep, tools/_tile_sweep.sh: 109 vs 107, 94 vs 91 TFLOP/s)
+  if (co <= 64) return (M >= 250000 && kred >= 96) ? 2 : 1;
   if (p.gdn) return (t && p.ksize == 3) ? 5 : 0;  // BN must equal c_out = 128
   auto score = [&](int bm, int bn, int slots, double base) {
     const long b = blocks(bm, bn);
@@ -684,16 +701,16 @@ static int pick_tile_auto(const aivc_conv_params &p) {
     return base * (double)b / (double)(rounds * slots);
   };
   if (p.mode == AIVC_MODE_GDN || p.mode == AIVC_MODE_IGDN) return 1;
-  double best = score(128, 128, 768, 0.80);
+  double best = score(128, 128, 512, 0.80);  // 176 registers: two workgroups per CU
   int tile = 0;
   const double s1 = score(64, 64, 1536, kred <= 256 ? 0.85 : 0.74);
   if (s1 > best) best = s1, tile = 1;
   if (t && p.ksize == 3) {
-    const double s5 = score(64, 128, 1024, 0.86);
+    const double s5 = score(64, 128, 1024, 0.75);
     if (s5 > best) best = s5, tile = 5;
   }
   if (!t && co % 128 == 0 && kred >= 512) {  // (transposed conv: the 4 parity classes have unequal K)
-    const double s4 = score(256, 128, 512, kred >= 1024 ? 0.95 : 0.86);
+    const double s4 = score(256, 128, 512, 0.78);  // since the lean epilogue / natural-K staging 128x128 is ahead (126 vs 118)
     if (s4 > best) best = s4, tile = 4;
   }
   return tile;

@@ -227,14 +227,22 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------ range decoder
-struct BitSrc {
-  const uint32_t *in;  // 4-byte aligned
-  uint32_t n_words;    // words that may be read (beyond: zeros)
-  uint32_t tail_bytes; // payload bytes in the last word (0 = all four)
-  uint32_t wi;         // next word index
-  uint32_t chunk;      // per-lane: word (wi & ~63) + lane
-  uint64_t win;        // upcoming bits, MSB aligned
-  uint32_t avail;
+// Per symbol torchac computes count = ((value - low + 1) * 2^16 - 1) / span, binary-searches the largest m with
+// cdf[m] <= count, then narrows  high = low - 1 + (span * cdf[m + 1] >> 16),  low = low + (span * cdf[m] >> 16).
+// Here every lane holds one CDF entry e and computes t = (span * e) >> 16 -- the very quantity the update needs.
+// cdf[m] <= count  <=>  e * span <= (d + 1) * 2^16 - 1  <=>  t <= d  with d = value - low, so the search is one
+// 32-bit compare + ballot + popcount, and the two t the update needs are already in registers (v_readlane): no
+// division, no 64-bit compare, no second multiplication.  The bit window keeps `value` as its upper half, so
+// renormalisation is a 64-bit shift.  All coder state is wave-uniform (SGPRs).  Instruction count is what
+// matters: the chain is serial by format, one dependent instruction after the other.
+struct BitWin {
+  const uint32_t *in;   // 4-byte aligned
+  uint32_t n_words;     // words that may be read (beyond: zeros)
+  uint32_t tail_bytes;  // payload bytes in the last word (0 = all four)
+  uint32_t wi;          // next word index
+  uint32_t chunk;       // per-lane: word (wi & ~63) + lane
+  uint64_t win;         // upcoming bits, MSB aligned; value = upper 32 bits
+  uint32_t avail;       // valid bits in win, kept in [33, 64]
   int lane;
   __device__ __forceinline__ void load_chunk() {
     const uint32_t idx = (wi & ~63u) + (uint32_t)lane;
@@ -256,104 +264,130 @@ struct BitSrc {
     win |= (uint64_t)next_word();
     avail = 64;
   }
-  __device__ __forceinline__ uint32_t take(uint32_t n) {  // n in [0, 32]
-    const uint32_t v = (uint32_t)((win >> 32) >> (32 - n));  // n = 0 -> shift by 32 of a 32-bit value in u64: 0
+  __device__ __forceinline__ uint32_t value() const { return (uint32_t)(win >> 32); }
+  __device__ __forceinline__ void consume(uint32_t n) {  // n in [0, 31]
     win <<= n;
     avail -= n;
     if (avail <= 32) {
       win |= (uint64_t)next_word() << (32 - avail);
       avail += 32;
     }
-    return v;
   }
 };
 
-constexpr int DEC_G = 8;      // symbols per prefetch group
+constexpr int DEC_D = 16;      // window prefetch depth (symbols): LDS ring of DEC_D slots
 constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
 
-struct RowRegs {
-  uint4 e;      // 8 consecutive uint16 CDF entries: 8*lane .. 8*lane+7     (full-row search)
-  uint32_t nx;  // entry 8*lane+8
-  uint32_t ew;  // entry DEC_WIN0 + lane                                      (window search)
-};
+// t = (span * e) >> 16 with span = hl + 1 (up to 2^32): e * hl + e < 2^48, exact in one v_mad_u64_u32
+__device__ __forceinline__ uint32_t scaled(uint32_t e, uint32_t hl) {
+  return (uint32_t)(((uint64_t)e * (uint64_t)hl + (uint64_t)e) >> 16);
+}
 
-// lanes whose CDF entry e satisfies e <= count, without computing count:
-//   e <= floor(num / span)  <=>  e * span <= num  <=>  e * (span - 1) + e <= num
-__device__ __forceinline__ unsigned long long le_mask(uint32_t e, uint32_t hl, uint64_t num) {
-  const uint64_t prod = (uint64_t)e * (uint64_t)hl + (uint64_t)e;
-  return __ballot(prod <= num);
+// LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS): no register, invisible to
+// the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at the next use of ANY
+// load result in this branchy loop, i.e. for the load it has just issued: measured 0.33 us per symbol, most of it
+// that wait).  Completion is counted by hand: one DMA per symbol, in order, `s_waitcnt vmcnt(DEC_D - 1)` before
+// the slot is read.  M0 (the LDS destination base) is written in the statement that uses it.
+__device__ __forceinline__ void window_dma(const uint16_t *gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
                                                           const uint16_t *__restrict__ rows, aivc_rc_batch batch,
                                                           uint16_t *__restrict__ sym) {
+  __shared__ uint32_t ring[DEC_D * 64];  // the DMA writes one dword per lane (a ushort load lands zero-extended at lane * 4)
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
   if (st.n_sym == 0) return;
   __builtin_amdgcn_s_setprio(3);  // latency-critical serial wave (see range_encode_kernel)
-  BitSrc src;
-  src.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
-  src.n_words = (st.in_len + 3u) / 4u;
-  src.tail_bytes = st.in_len & 3u;
-  src.lane = lane;
-  src.init();
+  BitWin bw;
+  bw.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
+  bw.n_words = (st.in_len + 3u) / 4u;
+  bw.tail_bytes = st.in_len & 3u;
+  bw.lane = lane;
+  bw.init();
   uint32_t low = 0, high = 0xFFFFFFFFu;
-  uint32_t value = src.take(32);
+  const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
 
-  // row bookkeeping for the prefetcher (row addresses never depend on coder state)
-  uint64_t pf_row = st.row_off;
-  uint32_t pf_in_plane = 0;
-  auto fetch = [&](RowRegs &r, bool valid) {
-    if (valid) {
-      const uint16_t *row = rows + pf_row * AIVC_CDF_ROW;
-      r.e = *reinterpret_cast<const uint4 *>(row + lane * 8);
-      r.nx = row[lane * 8 + 8];
-      r.ew = row[DEC_WIN0 + lane];
-      if (st.plane == 0) {
-        pf_row++;
-      } else if (++pf_in_plane == st.plane) {
-        pf_in_plane = 0;
-        pf_row++;
-      }
-    }
+  // Row of symbol i (row addresses never depend on coder state): one per symbol, or one per `plane` symbols.
+  // The prefetcher walks a per-lane pointer: + one row per symbol (or per `plane` symbols), parked on the last row
+  // once the stream's end is reached (the DMA count stays one per symbol).
+  const uint32_t plane = st.plane;
+  auto row_of = [&](uint32_t i) -> const uint16_t * {
+    const uint64_t r = st.row_off + (plane ? (uint64_t)(i / plane) : (uint64_t)i);
+    return rows + r * AIVC_CDF_ROW;
   };
+  const uint16_t *pf_ptr = rows + st.row_off * AIVC_CDF_ROW + DEC_WIN0 + lane;
+  uint32_t pf_i = 0, pf_in_plane = 0, pf_slot = 0;
+  auto prefetch = [&]() {
+    window_dma(pf_ptr, ring_base + pf_slot);
+    pf_slot = (pf_slot + 256u) & (DEC_D * 256u - 1u);
+    ++pf_i;
+    uint32_t step = pf_i < st.n_sym ? AIVC_CDF_ROW : 0u;
+    if (plane) {
+      ++pf_in_plane;
+      step = pf_in_plane == plane ? step : 0u;
+      pf_in_plane = pf_in_plane == plane ? 0u : pf_in_plane;
+    }
+    pf_ptr += step;
+  };
+#pragma unroll 1
+  for (uint32_t i = 0; i < DEC_D; ++i) prefetch();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 1) : "memory");
+  uint32_t ew_next = ring[lane] & 0xFFFFu;  // window of symbol 0
+  uint32_t rd_slot = 64;
 
   uint32_t mysym = 0;
-  auto decode_one = [&](const RowRegs &r, uint32_t i) {
+#pragma unroll 1
+  for (uint32_t i = 0; i < st.n_sym; ++i) {
+    const uint32_t ew = ew_next;
+    // window of symbol i + 1 (its DMA was issued DEC_D - 1 symbols ago): read now, used in the next iteration, so
+    // the LDS latency hides behind this symbol's arithmetic; then refill the slot symbol i was read from
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 2) : "memory");
+    ew_next = ring[rd_slot + lane] & 0xFFFFu;
+    rd_slot = (rd_slot + 64u) & (DEC_D * 64u - 1u);
     const uint32_t hl = high - low;  // span - 1
-    const uint64_t num = ((((uint64_t)value - (uint64_t)low) + 1) << 16) - 1;
-    uint32_t m, c_lo, c_hi;
-    // fast path: entries are strictly increasing, so the lanes with entry <= count form a prefix
-    const uint32_t cw = (uint32_t)__builtin_popcountll(le_mask(r.ew, hl, num));
-    if (cw != 0 && cw != 64) {
+    const uint32_t d = bw.value() - low;
+    uint32_t m, t_lo, t_hi;
+    // fast path: entries are strictly increasing, so the lanes with t <= d form a prefix
+    const uint32_t tw = scaled(ew, hl);
+    const uint32_t cw = (uint32_t)__builtin_popcountll(__ballot(tw <= d));
+    prefetch();  // after the use of `ew`: its LDS read has returned before the slot is handed to the next DMA
+    if (cw - 1u < 63u) {
       m = (uint32_t)DEC_WIN0 - 1u + cw;
-      c_lo = rl(r.ew, (int)cw - 1);
-      c_hi = rl(r.ew, (int)cw);
+      t_lo = rl(tw, (int)cw - 1);
+      t_hi = rl(tw, (int)cw);
     } else {
-      // symbol outside [-32, 30]: search the whole row (8 entries per lane)
-      const uint4 e = r.e;
-      const uint32_t total =
-          (uint32_t)__builtin_popcountll(le_mask(e.x & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.x >> 16, hl, num)) +
-          (uint32_t)__builtin_popcountll(le_mask(e.y & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.y >> 16, hl, num)) +
-          (uint32_t)__builtin_popcountll(le_mask(e.z & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.z >> 16, hl, num)) +
-          (uint32_t)__builtin_popcountll(le_mask(e.w & 0xFFFFu, hl, num)) + (uint32_t)__builtin_popcountll(le_mask(e.w >> 16, hl, num));
+      // symbol outside [-32, 30]: fetch and search the whole row (8 entries per lane); rare
+      const uint16_t *row = row_of(i);
+      const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
+      const uint32_t nx = row[lane * 8 + 8];
+      uint32_t t[9];
+      t[0] = scaled(e.x & 0xFFFFu, hl); t[1] = scaled(e.x >> 16, hl);
+      t[2] = scaled(e.y & 0xFFFFu, hl); t[3] = scaled(e.y >> 16, hl);
+      t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
+      t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
+      t[8] = scaled(nx, hl);
+      uint32_t total = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
       m = total > 0 ? total - 1 : 0;
       const int L = (int)(m >> 3);
       const uint32_t idx = m & 7u;
-      const uint64_t lo64 = (uint64_t)rl(e.x, L) | ((uint64_t)rl(e.y, L) << 32);
-      const uint64_t hi64 = (uint64_t)rl(e.z, L) | ((uint64_t)rl(e.w, L) << 32);
-      const uint32_t nxL = rl(r.nx, L);
-      const uint32_t pos = idx * 16u;
-      c_lo = (uint32_t)((pos < 64 ? lo64 >> pos : hi64 >> (pos - 64)) & 0xFFFFu);
-      const uint32_t pos1 = pos + 16u;
-      c_hi = idx == 7 ? nxL : (uint32_t)((pos1 < 64 ? lo64 >> pos1 : hi64 >> (pos1 - 64)) & 0xFFFFu);
-      if (m == 511u) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign streams
-        const uint64_t p512 = (uint64_t)nxL * (uint64_t)hl + (uint64_t)nxL;
-        if (p512 <= num) {
-          m = 512u;
-          c_lo = nxL;
-          c_hi = 0x10000u;
-        }
+      uint32_t s_lo = t[0], s_hi = t[1];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        s_lo = idx == (uint32_t)k ? t[k] : s_lo;
+        s_hi = idx == (uint32_t)k ? t[k + 1] : s_hi;
+      }
+      t_lo = rl(s_lo, L);
+      t_hi = rl(s_hi, L);
+      if (m == 511u && t_hi <= d) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign
+        m = 512u;                    // streams -- its upper bound is 2^16, i.e. t = span: high stays
+        t_lo = t_hi;
+        t_hi = hl + 1u;
       }
     }
     if (lane == (int)(i & 63u)) mysym = m;
@@ -362,39 +396,25 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
       if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
     }
     if (i != st.n_sym - 1) {
-      const uint64_t span = (uint64_t)hl + 1;
-      high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
-      low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
+      high = low + t_hi - 1u;
+      low = low + t_lo;
+      // E1 / E2: shift out the leading bits on which low and high agree
       const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
       low <<= n;
       high = (high << n) | ((1u << n) - 1u);
-      value = (uint32_t)(((uint64_t)value << n)) | src.take(n);
+      bw.consume(n);
+      // E3: positions where (low, high) = (01.., 10..) straddle the middle
       const uint32_t y = (low & ~high) << 1;
       const uint32_t m3 = (uint32_t)__builtin_clz(~y);
       if (m3 > 0) {
         low = (low << m3) & 0x7FFFFFFFu;
         high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
-        value = ((value << m3) ^ 0x80000000u) | src.take(m3);
+        bw.consume(m3);
+        bw.win ^= 0x8000000000000000ull;
       }
     }
-  };
-
-  // two register buffers, used alternately: while one group is decoded the next one is in flight
-  RowRegs bufA[DEC_G], bufB[DEC_G];
-#pragma unroll
-  for (int g = 0; g < DEC_G; ++g) fetch(bufA[g], (uint32_t)g < st.n_sym);
-  for (uint32_t base = 0; base < st.n_sym; base += 2 * DEC_G) {
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g) fetch(bufB[g], base + DEC_G + g < st.n_sym);
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g)
-      if (base + g < st.n_sym) decode_one(bufA[g], base + g);
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g) fetch(bufA[g], base + 2 * DEC_G + g < st.n_sym);
-#pragma unroll
-    for (int g = 0; g < DEC_G; ++g)
-      if (base + DEC_G + g < st.n_sym) decode_one(bufB[g], base + DEC_G + g);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
 }  // namespace aivc

@@ -103,7 +103,16 @@ def calibrate_operating_point(model, device, active_y=(6, 12), target_std=0.8, s
     with torch.no_grad():
         for (name, net), n_act in zip(nets.items(), active_y):
             y = run_nhwc(net.g_a, inputs[name]).reshape(-1, net.nb_ft_y)
-            mean, std = y.mean(0), y.std(0).clamp_min(1e-6)
+            # statistics with exactly rounded sums (math.fsum) on the host: the encode and decode CLIs rebuild this
+            # model in separate processes, possibly on different GPUs -- a reduction whose order depends on the
+            # device or the torch build could move a weight by an ulp and desynchronise the entropy decoder.
+            # y itself is bit-reproducible (fixed-order HIP kernels).
+            cols = y.double().cpu().numpy().T
+            n_s = cols.shape[1]
+            m64 = [math.fsum(c) / n_s for c in cols]
+            s64 = [max(math.sqrt(math.fsum((v - m) * (v - m) for v in c) / (n_s - 1)), 1e-6) for c, m in zip(cols, m64)]
+            mean = torch.tensor(m64, dtype=torch.float64).float().to(device)
+            std = torch.tensor(s64, dtype=torch.float64).float().to(device)
             scale = torch.full_like(std, 0.02) / std
             scale[:n_act] = target_std / std[:n_act]
             last = [m for m in net.g_a.modules() if isinstance(m, torch.nn.Conv2d)][-1]
