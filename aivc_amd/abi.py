@@ -28,12 +28,15 @@ FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 _f = C.c_void_p  # every buffer pointer travels as an integer address
 
 
+CONV_SPARSE4 = 1  # aivc_conv_params.flags: every 4th stored input channel is zero (images padded 3 -> 4)
+
+
 class ConvParams(C.Structure):
     _fields_ = [('mode', C.c_int32), ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('n', C.c_int32), ('h_in', C.c_int32), ('w_in', C.c_int32), ('c_in', C.c_int32),
                 ('h_out', C.c_int32), ('w_out', C.c_int32), ('c_out', C.c_int32),
                 ('act1', C.c_int32), ('act2', C.c_int32), ('algo', C.c_int32), ('gdn', C.c_int32),
-                ('reserved', C.c_int32),
+                ('flags', C.c_int32),
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
                 ('gdn_beta', _f), ('gdn_gamma', _f)]
 

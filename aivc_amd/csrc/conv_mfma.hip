@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
 
   // one K-tile of MFMAs out of LDS (measured in isolation, tools/mfma_probe.hip: this loop keeps the
   // matrix pipe 98% busy, i.e. what is lost in the whole kernel is lost outside of it)
-  auto mma_octs = [&](floatx16 (&c)[TM][TN], int buf_off, int o_lo, int o_hi) {
+  // AIVC_CONV_SPARSE4 (3-channel images stored as 4 channels): reduction indices kk with kk % 4 == 3 multiply a
+  // zero input -- step s = 3 of every octet (k = 8 o + 3 and 8 o + 7) is an exact no-op and is not issued.
+  const bool skip3 = !FASTK && (p.flags & AIVC_CONV_SPARSE4) != 0;
+  auto mma_octs = [&](floatx16 (&c)[TM][TN], int buf_off, int o_lo, int o_hi, bool skip) {
 #pragma unroll
     for (int o = o_lo; o < o_hi; ++o) {
       float4 af[TM], bf[TN];
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_frag + buf_off + j * 32 * LDS_STRIDE + o * 8);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (s == 3 && skip) continue;  // wave-uniform
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float av = s == 0 ? af[i].x : (s == 1 ? af[i].y : (s == 2 ? af[i].z : af[i].w));
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       }
     }
   };
-  auto mma_tile = [&](floatx16 (&c)[TM][TN]) { mma_octs(c, 0, 0, OCT); };
+  auto mma_tile = [&](floatx16 (&c)[TM][TN], bool skip) { mma_octs(c, 0, 0, OCT, skip); };
 
   load_tile(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     store_tile_b();
     __syncthreads();
     if (kt + 1 < nkt) load_tile(kt + 1);
-    mma_tile(acc);
+    mma_tile(acc, skip3);
   }
 
 
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
       store_tile_b();
       __syncthreads();
       if (kt2 + 1 < nk2) load_gamma(kt2 + 1);
-      mma_tile(acc2);
+      mma_tile(acc2, false);  // the GDN reduction runs over all (real) channels
     }
   }
 

@@ -119,9 +119,11 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     for t, nm in ((mul, 'mul'), (res, 'res')):
         if t is not None and tuple(t.shape) != tuple(y.shape):
             raise AivcNativeError('conv2d: %s shape %s != output shape %s' % (nm, tuple(t.shape), tuple(y.shape)))
+    # 3-channel images stored as 4: the zero pad channels are exact no-ops the MFMA kernels may skip
+    flags = abi.CONV_SPARSE4 if cmap is not None and all(ci % 4 != 3 for ci in cmap) else 0
     if gdn is not None:
         g_beta, g_gamma, g_inv = gdn
-        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 2 if g_inv else 1, 0,
+        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 2 if g_inv else 1, flags,
                            _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(g_beta), _p(g_gamma))
         from ._lib import load
         if load()['aivc_conv2d_variant'](C.byref(p)) < 0:  # not fusable for this shape: two launches
@@ -129,7 +131,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
             return globals()['gdn'](t, g_beta, g_gamma, inverse=g_inv, res=res, algo=algo) if act1 == 0 and \
                 act2 == 0 and mul is None else _unsupported_gdn_epilogue()
     else:
-        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, 0,
+        p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, flags,
                            _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), None, None)
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())

@@ -43,6 +43,8 @@
 extern "C" {
 #endif
 
+#define AIVC_CONV_SPARSE4 1
+
 /* position inside a group of 8 reduction indices visited at step i (see the arithmetic contract above) */
 #define AIVC_K_ORDER(i) ((((i) & 1) << 2) | ((i) >> 1))
 
@@ -95,7 +97,9 @@ typedef struct aivc_conv_params {
   int32_t act2;                /* applied after the residual addition   */
   int32_t algo;                /* AIVC_ALGO_* (AUTO picks MFMA when the shape allows) */
   int32_t gdn;                 /* CONV/TCONV only: 0 none, 1 GDN, 2 inverse GDN fused after the bias */
-  int32_t reserved;
+  int32_t flags;               /* AIVC_CONV_SPARSE4: every 4th stored input channel (ci % 4 == 3) is zero in x --
+                                * the layout of 3-channel images padded to 4; those terms are exact no-ops of the
+                                * fmaf chain and the MFMA kernels skip them (a hint: results never depend on it) */
   const float *x;    /* [n][h_in][w_in][c_in] */
   const float *w;    /* [c_out][ksize][ksize][c_in]  (OHWI; TCONV: w[co][ky][kx][ci] = torch weight[ci][co][ky][kx]) */
   const float *bias; /* [c_out] or NULL */
