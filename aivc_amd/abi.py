@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 AIVC_OK = 0
 ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
@@ -39,6 +39,13 @@ class ConvParams(C.Structure):
                 ('flags', C.c_int32),
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
                 ('gdn_beta', _f), ('gdn_gamma', _f)]
+
+
+MAX_IMAGES = 3
+
+
+class ImageSrc(C.Structure):
+    _fields_ = [('y', _f), ('u', _f), ('v', _f), ('f', _f), ('f_channels', C.c_int32), ('reserved', C.c_int32)]
 
 
 class MapList(C.Structure):
@@ -76,6 +83,7 @@ PROTOTYPES = {
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
+    'aivc_pack_images': [C.POINTER(ImageSrc), _i32, _i32, _i32, _i32, _f],
     'aivc_frame_to_yuv420': [_f, _i32, _i32, _i32, _i32, _f, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f],
     'aivc_downsample2x': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'aivc_warp_blend': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],

@@ -57,18 +57,10 @@ class FrameCodec:
 
     @staticmethod
     def _images(parts, h, w, device):
-        """Concatenate 3-channel images, each padded to 4 stored channels, WITHOUT cat / pad kernels:
-        parts are plane dicts (converted in place), NHWC [n,h,w,4] tensors (copied into their slot) or
+        """Concatenate 3-channel images, each padded to 4 stored channels, in ONE kernel (aivc_pack_images):
+        parts are plane dicts (converted), NHWC [n,h,w,4] float tensors (first 3 channels copied) or
         None (zeros).  The result carries the stored position of every real channel for the first conv."""
-        n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
-        buf = torch.zeros((n, h, w, 4 * len(parts)), dtype=torch.float32, device=device)
-        for i, p in enumerate(parts):
-            if isinstance(p, dict):
-                ops.yuv420_to_444(p['y'], p['u'], p['v'], c_off=4 * i, out=buf)
-            elif p is not None:
-                buf[..., 4 * i:4 * i + 4] = p
-        buf._aivc_cmap = tuple(4 * i + c for i in range(len(parts)) for c in range(3))
-        return buf
+        return ops.pack_images(parts, h, w, device)  # one launch, contiguous stores (no memset, no per-image pass)
 
     def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
         """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts

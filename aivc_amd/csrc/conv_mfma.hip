@@ -620,7 +620,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     if (heavy) {
       __threadfence_block();  // the pass below re-reads this thread's own stores
       float *y2 = p.y;
-#pragma unroll 1
+      // 4 outputs per trip: their loads overlap (one per trip left the pass latency-bound: a dependent
+      // load - sigmoid - store chain per output), the code still holds only 4 copies of the fp64 sigmoid
+#pragma unroll 4
       for (int q = 0; q < TM * 16 * TN; ++q) {
         const int j = q % TN, r = (q / TN) & 15, i = q / (TN * 16);
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -695,6 +697,8 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   //   fused GDN, c_out = 128 -> 128x128, or 64x128 for the short reductions of a transposed 3x3
   //   otherwise score the candidates by efficiency class x block-count balance
   if (co <= 32) return 3;
+  // attention gates (sigmoid): their per-output pass wants many small tiles (16 outputs per thread)
+  if ((p.act1 == AIVC_ACT_SIGMOID || p.act2 == AIVC_ACT_SIGMOID) && !p.gdn) return 1;
   // c_out = 64: 256x64 (four waves stacked along M, 4 accumulators each) once there are >= ~1000 such tiles and
   // the reduction is long; else the small tile (r02 sweep, tools/_tile_sweep.sh: 109 vs 107, 94 vs 91 TFLOP/s)
   if (co <= 64) return (M >= 250000 && kred >= 96) ? 2 : 1;

@@ -144,26 +144,26 @@ __global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__
 // ------------------------------------------------------------------ range encoder
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// MSB-first bit packer.  All state is wave-uniform; every lane issues the same store (one
-// transaction), which keeps the hot loop free of exec-mask branches.  The word under construction
-// is re-stored on every call and simply overwritten until it is complete.
+// MSB-first bit packer.  All state is wave-uniform (SGPRs); a 32-bit word is stored (every lane issues the same
+// store: one transaction) only when it is complete -- at the ~1 bit per symbol of these latents that is one store
+// per ~30 symbols instead of one per call -- behind a wave-uniform branch.  finish() writes the partial last word.
 struct BitSink {
   uint32_t *out;       // 4-byte aligned
   uint32_t cap_words;  // capacity in 32-bit words (>= 1)
   uint32_t n_words;
-  uint64_t acc;
-  uint32_t nbits;  // < 32 between calls
+  uint64_t acc;        // the low `nbits` bits are pending output
+  uint32_t nbits;      // < 32 between calls
   uint32_t overflow;
   __device__ __forceinline__ void put(uint32_t bits, uint32_t nb) {  // nb in [0, 32]
     acc = (acc << nb) | (uint64_t)bits;
     nbits += nb;
-    const bool full = nbits >= 32;
-    const uint32_t w = full ? (uint32_t)(acc >> (nbits - 32)) : (uint32_t)(acc << (32 - nbits));
-    const uint32_t idx = n_words < cap_words ? n_words : cap_words - 1;
-    overflow |= (uint32_t)(n_words >= cap_words);
-    out[idx] = __builtin_bswap32(w);
-    n_words += full ? 1u : 0u;
-    nbits -= full ? 32u : 0u;
+    if (nbits >= 32) {
+      nbits -= 32;
+      const uint32_t w = (uint32_t)(acc >> nbits);
+      if (n_words < cap_words) out[n_words] = __builtin_bswap32(w);
+      else overflow = 1;
+      n_words++;
+    }
   }
   __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count) {
     while (count > 0) {
@@ -171,6 +171,13 @@ struct BitSink {
       const uint32_t ones = r == 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
       put(bit ? ones : 0u, r);
       count -= r;
+    }
+  }
+  __device__ __forceinline__ void finish() {  // bits left over after the last complete word: MSB aligned, zero padded
+    if (nbits > 0) {
+      const uint32_t w = (uint32_t)(acc << (32 - nbits));
+      if (n_words < cap_words) out[n_words] = __builtin_bswap32(w);
+      else overflow = 1;
     }
   }
 };
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
       const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
       const uint32_t top = (uint32_t)(((uint64_t)low << n) >> 32);  // the n leading bits of low
       if (pending == 0) {
-        sink.put(top, n);
+        if (n > 0) sink.put(top, n);
       } else if (n > 0) {
         const uint32_t b0 = low >> 31;
         sink.put(b0, 1);
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
   const uint32_t fb = low < 0x40000000u ? 0u : 1u;
   sink.put(fb, 1);
   sink.put_run(fb ^ 1u, pending);
-  sink.put(0u, 0u);  // store the bits left over after the last completed word (MSB aligned, zero padded)
+  sink.finish();
   // count the bytes of the partial last word
   const uint32_t total = sink.n_words * 4u + (sink.nbits + 7u) / 8u;
   if (total > st.out_cap) sink.overflow = 1;

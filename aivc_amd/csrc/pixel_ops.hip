@@ -7,35 +7,91 @@
 namespace aivc {
 
 // ---------------------------------------------------------------- 4:2:0 -> 4:4:4 (InputLayer)
+// One workgroup converts a run of 1024 pixels of one row, 4 pixels per thread spaced 256 apart (so every load and
+// every 16-byte store of a wave is contiguous across its lanes); no integer division (row and image come from
+// the grid), and for 8-bit planes the level k / 255.0f -- which must be the correctly rounded quotient the
+// reference's to_tensor produces -- from a 256-entry table built once per workgroup in LDS instead of three IEEE
+// divisions per pixel.
 template <typename T>
 __global__ __launch_bounds__(256) void yuv420_to_444_kernel(const T *__restrict__ y, const T *__restrict__ u,
                                                             const T *__restrict__ v, int n, int h, int w,
                                                             float *__restrict__ out, int c_store, int c_off,
                                                             int zero_pad) {
-  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)n * h * w;
-  if (pix >= total) return;
-  const int c = (int)(pix % w), r = (int)((pix / w) % h), b = (int)(pix / ((size_t)w * h));
-  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
-  const size_t ci = ((size_t)b * hc + r / 2) * wc + c / 2;
-  float fy, fu, fv;
+  __shared__ float lut[256];
   if (sizeof(T) == 1) {
-    fy = (float)y[pix] / 255.0f;
-    fu = (float)u[ci] / 255.0f;
-    fv = (float)v[ci] / 255.0f;
-  } else {
-    fy = (float)y[pix];
-    fu = (float)u[ci];
-    fv = (float)v[ci];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
   }
-  float *o = out + pix * c_store + c_off;
-  if (zero_pad && ((c_store & 3) == 0) && ((c_off & 3) == 0)) {
-    *reinterpret_cast<float4 *>(o) = make_float4(fy, fu, fv, 0.0f);
-  } else {
-    o[0] = fy;
-    o[1] = fu;
-    o[2] = fv;
-    if (zero_pad) o[3] = 0.0f;
+  const int r = blockIdx.y, b = blockIdx.z;
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const T *yr = y + ((size_t)b * h + r) * w;
+  const T *ur = u + ((size_t)b * hc + r / 2) * wc;
+  const T *vr = v + ((size_t)b * hc + r / 2) * wc;
+  float *orow = out + ((size_t)b * h + r) * w * c_store + c_off;
+  const bool vec = zero_pad && ((c_store & 3) == 0) && ((c_off & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = blockIdx.x * 1024 + i * 256 + (int)threadIdx.x;
+    if (x < w) {
+      float fy, fu, fv;
+      if (sizeof(T) == 1) {
+        fy = lut[(uint8_t)yr[x]];
+        fu = lut[(uint8_t)ur[x >> 1]];
+        fv = lut[(uint8_t)vr[x >> 1]];
+      } else {
+        fy = (float)yr[x];
+        fu = (float)ur[x >> 1];
+        fv = (float)vr[x >> 1];
+      }
+      float *o = orow + (size_t)x * c_store;
+      if (vec) {
+        *reinterpret_cast<float4 *>(o) = make_float4(fy, fu, fv, 0.0f);
+      } else {
+        o[0] = fy;
+        o[1] = fu;
+        o[2] = fv;
+        if (zero_pad) o[3] = 0.0f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- padded multi-image conv input
+struct PackArgs {
+  aivc_image_src src[AIVC_MAX_IMAGES];
+  int n_img, n, h, w;
+  float *out;
+};
+// A lane owns one 16-byte chunk = (pixel, image): consecutive lanes write consecutive chunks of the row, so each
+// store instruction covers 1024 contiguous bytes whatever the number of images (a per-image pass stores 16 of
+// every 32 / 48 bytes).  Row and batch index come from the grid; k / 255.0f from a table in LDS.
+__global__ __launch_bounds__(256) void pack_images_kernel(PackArgs a) {
+  __shared__ float lut[256];
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
+  const int r = blockIdx.y, b = blockIdx.z;
+  const int w = a.w, h = a.h, hc = (h + 1) / 2, wc = (w + 1) / 2, ni = a.n_img;
+  const int chunks = w * ni;
+  float4 *orow = reinterpret_cast<float4 *>(a.out + ((size_t)b * h + r) * (size_t)w * 4 * ni);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = blockIdx.x * 1024 + i * 256 + (int)threadIdx.x;
+    if (c >= chunks) break;
+    const int x = ni == 1 ? c : (ni == 2 ? c >> 1 : (int)(((unsigned)c * 43691u) >> 17));  // c / 3 for c < 98304
+    const int img = c - x * ni;
+    const aivc_image_src &s = a.src[img];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s.y) {
+      v.x = lut[s.y[((size_t)b * h + r) * w + x]];
+      v.y = lut[s.u[((size_t)b * hc + r / 2) * wc + (x >> 1)]];
+      v.z = lut[s.v[((size_t)b * hc + r / 2) * wc + (x >> 1)]];
+    } else if (s.f) {
+      const float *f = s.f + (((size_t)b * h + r) * w + x) * s.f_channels;
+      v.x = f[0];
+      v.y = f[1];
+      v.z = f[2];
+    }
+    orow[c] = v;
   }
 }
 
@@ -314,7 +370,7 @@ AIVC_EXPORT int aivc_yuv420_to_444(const float *y, const float *u, const float *
                                    aivc_stream_t stream) {
   if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
   if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
-  hipLaunchKernelGGL(yuv420_to_444_kernel<float>, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream),
+  hipLaunchKernelGGL(yuv420_to_444_kernel<float>, dim3(cdiv((size_t)w, 1024), h, n), dim3(256), 0, to_stream(stream),
                      y, u, v, n, h, w, out, c_store, c_off, zero_pad);
   return check_launch("yuv420_to_444");
 }
@@ -324,9 +380,29 @@ AIVC_EXPORT int aivc_yuv420u8_to_444(const uint8_t *y, const uint8_t *u, const u
                                      aivc_stream_t stream) {
   if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
   if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
-  hipLaunchKernelGGL(yuv420_to_444_kernel<uint8_t>, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(yuv420_to_444_kernel<uint8_t>, dim3(cdiv((size_t)w, 1024), h, n), dim3(256), 0,
                      to_stream(stream), y, u, v, n, h, w, out, c_store, c_off, zero_pad);
   return check_launch("yuv420u8_to_444");
+}
+
+AIVC_EXPORT int aivc_pack_images(const aivc_image_src *src, int32_t n_img, int32_t n, int32_t h, int32_t w, float *out,
+                                 aivc_stream_t stream) {
+  if (!src || !out || n_img < 1 || n_img > AIVC_MAX_IMAGES || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
+  if ((long)w * n_img >= 98304 || h > 65535 || n > 65535) return AIVC_ERR_UNSUPPORTED;
+  PackArgs a;
+  for (int i = 0; i < AIVC_MAX_IMAGES; ++i) a.src[i] = aivc_image_src{nullptr, nullptr, nullptr, nullptr, 0, 0};
+  for (int i = 0; i < n_img; ++i) {
+    a.src[i] = src[i];
+    if (src[i].y && (!src[i].u || !src[i].v)) return AIVC_ERR_ARG;
+    if (!src[i].y && src[i].f && src[i].f_channels < 3) return AIVC_ERR_ARG;
+  }
+  a.n_img = n_img;
+  a.n = n;
+  a.h = h;
+  a.w = w;
+  a.out = out;
+  hipLaunchKernelGGL(pack_images_kernel, dim3(cdiv((size_t)w * n_img, 1024), h, n), dim3(256), 0, to_stream(stream), a);
+  return check_launch("pack_images");
 }
 
 AIVC_EXPORT int aivc_frame_to_yuv420(const float *x, int32_t n, int32_t hx, int32_t wx, int32_t cx, const float *skip,

@@ -198,6 +198,29 @@ def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
     return out
 
 
+def pack_images(parts, h, w, device):
+    """parts: up to 3 sources, each a dict of uint8 planes {'y','u','v'} ([n,h,w] / [n,ceil(h/2),ceil(w/2)]), a
+    float NHWC tensor [n,h,w,c>=3] (its first 3 channels are taken) or None (zeros) -> NHWC [n,h,w,4*len(parts)]
+    with every image stored as (c0, c1, c2, 0); carries the stored position of the real channels for the conv."""
+    n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
+    arr = (abi.ImageSrc * abi.MAX_IMAGES)()
+    keep = []
+    for i, p in enumerate(parts):
+        if isinstance(p, dict):
+            y, u, v = (_dev(p[k], torch.uint8, k) for k in 'yuv')
+            keep += [y, u, v]
+            arr[i].y, arr[i].u, arr[i].v = y.data_ptr(), u.data_ptr(), v.data_ptr()
+        elif p is not None:
+            f = _dev(p, torch.float32, 'image')
+            keep.append(f)
+            arr[i].f, arr[i].f_channels = f.data_ptr(), f.shape[-1]
+    out = torch.empty((n, h, w, 4 * len(parts)), dtype=torch.float32, device=device)
+    nb = n * h * w * (16 * len(parts) + sum(1.5 if isinstance(p, dict) else (12 if p is not None else 0) for p in parts))
+    _hbm_profiled('pack_images', nb, lambda: call('aivc_pack_images', arr, len(parts), n, h, w, _p(out), _stream()))
+    out._aivc_cmap = tuple(4 * i + c for i in range(len(parts)) for c in range(3))
+    return out
+
+
 def frame_to_yuv420(x, h, w, skip=None, want_float=True, want_u8=True):
     x = _dev(x, torch.float32, 'x')
     skip = _dev(skip, torch.float32, 'skip')

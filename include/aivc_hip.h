@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 3 */
+int aivc_abi_version(void); /* currently 4 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -152,6 +152,22 @@ int aivc_yuv420_to_444(const float *y, const float *u, const float *v, int32_t n
 int aivc_yuv420u8_to_444(const uint8_t *y, const uint8_t *u, const uint8_t *v, int32_t n,
                          int32_t h, int32_t w, float *out, int32_t c_store, int32_t c_off,
                          int32_t zero_pad, aivc_stream_t stream);
+
+/* Input of the first conv of a transform: up to AIVC_MAX_IMAGES 3-channel images side by side, each stored as 4
+ * channels (c0, c1, c2, 0): out[n][h][w][4 * n_img].  An image comes from 8-bit 4:2:0 planes (InputLayer
+ * semantics as aivc_yuv420u8_to_444), from the first 3 channels of an NHWC float tensor f[n][h][w][f_channels]
+ * (the prediction alpha * x_warp), or is all zero (every pointer NULL: the missing reference of a P frame).
+ * One launch, every 16-byte store of a wave contiguous; replaces the cat / pad of the inputs of g_a and g_a_ref
+ * (src/real_life/decode.py:709-714, 631-636 and the encoder's mirror image). */
+#define AIVC_MAX_IMAGES 3
+typedef struct {
+  const uint8_t *y, *u, *v; /* planes [n][h][w], [n][ceil(h/2)][ceil(w/2)] x2, or NULL */
+  const float *f;           /* or an NHWC tensor [n][h][w][f_channels], or NULL */
+  int32_t f_channels;
+  int32_t reserved;
+} aivc_image_src;
+int aivc_pack_images(const aivc_image_src *src, int32_t n_img, int32_t n, int32_t h, int32_t w, float *out,
+                     aivc_stream_t stream);
 
 /* Reconstruction tail of Decoder.decode: x_hat = x[:, :h, :w, :3] (+ skip), OutputLayer
  * (U,V = bilinear x0.5, align_corners=False = 2x2 mean), replicate-pad U,V to ceil(h/2) x

@@ -176,6 +176,25 @@ def yuv420u8_to_444(y, u, v, c_store=3, c_off=0, out=None):
     return out
 
 
+def pack_images(parts, h, w):
+    """oracle twin of ops.pack_images: parts are dicts of uint8 planes [n,h,w], float NHWC arrays or None"""
+    n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
+    arr = (abi.ImageSrc * abi.MAX_IMAGES)()
+    keep = []
+    for i, p in enumerate(parts):
+        if isinstance(p, dict):
+            y, u, v = (np.ascontiguousarray(p[k], np.uint8) for k in 'yuv')
+            keep += [y, u, v]
+            arr[i].y, arr[i].u, arr[i].v = y.ctypes.data, u.ctypes.data, v.ctypes.data
+        elif p is not None:
+            f = _f32(p)
+            keep.append(f)
+            arr[i].f, arr[i].f_channels = f.ctypes.data, f.shape[-1]
+    out = np.empty((n, h, w, 4 * len(parts)), np.float32)
+    _chk(lib()['aivc_pack_images'](arr, len(parts), n, h, w, _p(out), None), 'aivc_pack_images')
+    return out
+
+
 def frame_to_yuv420(x, h, w, skip=None):
     """returns (y, u, v) fp32 8-bit levels and (y8, u8, v8) bytes"""
     x = _f32(x)

@@ -279,3 +279,34 @@ def test_fused_gdn_bit_exact(case, oracle, cuda):
     got = ops.conv2d(T(x, cuda), T(wt, cuda), T(bias, cuda), mode=mode, stride=s, pad=pad,
                      res=None if res is None else T(res, cuda), gdn=(T(beta, cuda), T(gamma, cuda), inv))
     eq(got, two)
+
+
+@pytest.mark.parametrize('h,w', [(9, 13), (16, 32), (35, 1030)])
+def test_pack_images_bit_exact(h, w, cuda, oracle):
+    """aivc_pack_images (padded multi-image input of the first convs) == oracle twin == per-image conversion"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(h * 1000 + w)
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    n = 2
+
+    def planes():
+        return {'y': rng.integers(0, 256, (n, h, w), dtype=np.uint8), 'u': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8),
+                'v': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8)}
+    a, b = planes(), planes()
+    f = rng.standard_normal((n, h, w, 4)).astype(np.float32)
+    dev = lambda p: {k: torch.from_numpy(p[k]).to(cuda) for k in 'yuv'}
+    for parts_np in ([a], [a, None], [a, b, None], [a, f], [a, b, a], [None, f, b]):
+        parts_t = [dev(p) if isinstance(p, dict) else (None if p is None else torch.from_numpy(p).to(cuda)) for p in parts_np]
+        got = ops.pack_images(parts_t, h, w, cuda)
+        want = oracle.pack_images(parts_np, h, w)
+        assert got._aivc_cmap == tuple(4 * i + c for i in range(len(parts_np)) for c in range(3))
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        # and the same as the per-image kernels
+        for i, p in enumerate(parts_np):
+            if isinstance(p, dict):
+                ref = ops.yuv420_to_444(parts_t[i]['y'], parts_t[i]['u'], parts_t[i]['v'], c_store=4)
+                assert torch.equal(got[..., 4 * i:4 * i + 4], ref)
+            elif p is None:
+                assert not got[..., 4 * i:4 * i + 4].any()
+            else:
+                assert torch.equal(got[..., 4 * i:4 * i + 3], parts_t[i][..., :3]) and not got[..., 4 * i + 3].any()
