@@ -172,7 +172,7 @@ def main():
     ap.add_argument('--frames', type=int, default=128, help='requested frames of the clip (BASELINE configs[3]: 128)')
     ap.add_argument('--scaling', choices=('auto', 'strong', 'weak'), default=os.environ.get('AIVC_BENCH_SCALING', 'auto'),
                     help='auto = strong (one clip over all GPUs) when N > 1')
-    ap.add_argument('--max-batch', type=int, default=8)
+    ap.add_argument('--max-batch', type=int, default=16)
     ap.add_argument('--entropy-streams', type=int, default=4, help='decoder: concurrent range-coder chains')
     ap.add_argument('--entropy-lookahead', type=int, default=2, help='decoder: dependency levels of entropy decoding issued ahead')
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
@@ -392,7 +392,7 @@ def main():
             'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%dx%d 8-bit YUV420, random access %s: one %d-frame clip = %d intra-period units of %d frames '
+            'config': {'workload': '%dx%d 8-bit YUV420, coding structure %s: one %d-frame clip = %d intra-period units of %d frames '
                                    '(%d coded frames, the last %d repeat the last frame) encoded + decoded per step; synthetic '
                                    'random-init stand-in for model ms_ssim-4 (widths %s), last analysis conv calibrated so that '
                                    '%d (MOFNet) / %d (CodecNet) of the %d y feature maps are non-zero (low-rate operating point); %s'
