@@ -185,12 +185,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    # validation aid for boxes with ONE GPU: AIVC_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # AIVC_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks per device) -- the whole N > 1 flow of this
+    # script (sharding, collectives, both scaling modes) then runs for real across processes; not a measurement
+    if os.environ.get('AIVC_BENCH_SINGLE_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or bool(os.environ.get('AIVC_FORCE_DIST'))  # (the env var exercises the RCCL path on 1 GPU)
+    backend = os.environ.get('AIVC_DIST_BACKEND', 'nccl')
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     strong = args.scaling == 'strong' or (args.scaling == 'auto')
 
     from aivc_amd import ops, parallel, synth
@@ -415,6 +424,8 @@ def main():
             out['weak_scaling'] = other
         if args.tiny:
             out['invalid'] = 'tiny debug model'
+        if use_dist and backend != 'nccl':
+            out['invalid'] = 'validation run over %s, not RCCL' % backend
         print(json.dumps(out))
     if use_dist:
         dist.barrier()  # the other ranks wait for rank 0's instrumented step before tearing RCCL down
