@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 AIVC_OK = 0
 ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
@@ -38,7 +38,8 @@ class ConvParams(C.Structure):
                 ('act1', C.c_int32), ('act2', C.c_int32), ('algo', C.c_int32), ('gdn', C.c_int32),
                 ('flags', C.c_int32),
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
-                ('gdn_beta', _f), ('gdn_gamma', _f)]
+                ('gdn_beta', _f), ('gdn_gamma', _f),
+                ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('reserved2', C.c_int32)]
 
 
 MAX_IMAGES = 3

@@ -19,7 +19,7 @@ int check_launch(const char *what) {
 }
 }  // namespace aivc
 
-AIVC_EXPORT int aivc_abi_version(void) { return 4; }
+AIVC_EXPORT int aivc_abi_version(void) { return 5; }
 AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
 
 static int validate_conv(const aivc_conv_params *p) {
@@ -49,6 +49,9 @@ static int validate_conv(const aivc_conv_params *p) {
     if (p->gdn < 0 || p->gdn > 2 || p->mode == AIVC_MODE_GDN || p->mode == AIVC_MODE_IGDN) return AIVC_ERR_ARG;
     if (!p->gdn_beta || !p->gdn_gamma) return AIVC_ERR_ARG;
   }
+  if (p->tail_c_out) {
+    if (p->tail_c_out < 0 || !p->tail_w || p->mode != AIVC_MODE_CONV || p->gdn || p->mul) return AIVC_ERR_ARG;
+  }
   return AIVC_OK;
 }
 
@@ -56,6 +59,10 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
+  if (p->tail_c_out) {
+    if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_tail_supported(*p)) return AIVC_ERR_UNSUPPORTED;
+    return aivc::conv2d_mfma_variant(*p);
+  }
   if (p->algo == AIVC_ALGO_DIRECT) return 0;
   if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin_variant(*p);
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
@@ -68,6 +75,10 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   hipStream_t s = aivc::to_stream(stream);
   if (p->gdn) {  // fused (I)GDN exists on the MFMA path only
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p)) return AIVC_ERR_UNSUPPORTED;
+    return aivc::conv2d_mfma(*p, s);
+  }
+  if (p->tail_c_out) {  // fused 1x1 tail: MFMA path only
+    if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_tail_supported(*p)) return AIVC_ERR_UNSUPPORTED;
     return aivc::conv2d_mfma(*p, s);
   }
   if (p->algo == AIVC_ALGO_DIRECT) return aivc::conv2d_direct(*p, s);

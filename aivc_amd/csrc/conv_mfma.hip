@@ -53,9 +53,15 @@ __device__ unsigned long long aivc_dbg_t[8 * 8192];
 #define DBG_T(i)
 #endif
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
-__global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(MfmaArgs a) {
+#ifndef AIVC_TAIL_WAVES
+#define AIVC_TAIL_WAVES 2  // waves per SIMD the fused-tail kernel is compiled for (3 spills; measured equal)
+#endif
+constexpr int TAIL_N = 128;  // output channels of the fused 1x1 tail (the bottleneck blocks: 64 -> 128)
+
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false>
+__global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 1))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static_assert(!TAIL || (MODE == AIVC_MODE_CONV && !FUSE && FASTK && BN == 64 && BN % BK == 0), "fused tail: conv, c_out 64");
   constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
   constexpr int UB = (BN * OCT + 255) / 256;  // ... for B
   constexpr bool B_FULL = (BN * OCT) % 256 == 0;  // every thread stages a B unit: no exec masking
@@ -404,6 +410,169 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
     }
   }
 
+  // ---- fused 1x1 tail: y = act2(W3 . act1(acc + bias) + b3 (+ res)), TAIL_N output channels ---------------
+  // Same mechanism as the fused GDN: the activated outputs t of this conv (BN == c_out: a workgroup owns every
+  // channel of its pixels) go through the A tile buffer 32 channels at a time, the 1x1 weights stream through
+  // the B buffer, a second MFMA GEMM [BM x c_out] x [c_out x TAIL_N] accumulates in the order of a stand-alone
+  // 1x1 launch (K tiles of 32, octets in AIVC_K_ORDER) -- bit identical to the two launches, and the c_out-wide
+  // intermediate never goes to memory.
+  if constexpr (TAIL) {
+    constexpr int TN2 = TAIL_N / (32 * WN);
+    constexpr int UB2 = TAIL_N * OCT / 256;
+    float4 rt[UB2][2];
+    auto load_w3 = [&](int kt2) {
+#pragma unroll
+      for (int j = 0; j < UB2; ++j) {
+        const int u = tid + 256 * j;
+        const float *src = p.tail_w + (size_t)(u / OCT) * Cout + kt2 * BK + (u % OCT) * 8;
+        rt[j][0] = *reinterpret_cast<const float4 *>(src);
+        rt[j][1] = *reinterpret_cast<const float4 *>(src + 4);
+      }
+    };
+    load_w3(0);
+    // The residual operand is fetched while the tail GEMM runs, 32 output rows (one accumulator row block) at a
+    // time into the registers the K loop no longer needs: fetched in the epilogue, each output row was one
+    // dependent HBM round trip (measured: 30 % of a workgroup's time, 25 us for 128 KB).
+    const int col = wn * TN2 * 32 + (lane & 31);
+    const int lrow = 4 * (lane >> 5);
+    const int wrow = wm * TM * 32 + lrow;    // first tile row of this lane
+    const int rows_left = M - m0 - wrow;     // rows of this lane that exist, counted from wrow
+    const bool whole = m0 + BM <= M;
+    const bool has_res = p.res != nullptr;
+    float rv[TM][16][TN2];
+    auto fetch_res = [&](int i) {
+      if (!has_res) return;
+      const float *rbase = p.res + (size_t)m0 * TAIL_N + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+        const int row = (whole || k < rows_left) ? wrow + k : 0;  // rows beyond M: any valid address, never stored
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) rv[i][r][j] = rbase[(size_t)row * TAIL_N + 32 * j];
+      }
+    };
+    {
+      const int a1 = p.act1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float b = p.bias[(wn * TN + j) * 32 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r] + b;
+            const float neg = a1 == AIVC_ACT_LEAKY ? v * 0.01f : (a1 == AIVC_ACT_RELU ? 0.0f : v);
+            acc[i][j][r] = v > 0.0f ? v : neg;
+          }
+      }
+    }
+    fetch_res(0);
+    floatx16 acc3[TM][TN2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.0f;
+    const float *b2_frag = Bs + (wn * TN2 * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    constexpr int nk2 = BN / BK;
+#pragma unroll
+    for (int kt2 = 0; kt2 < nk2; ++kt2) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (wn * TN + j == kt2) {  // wave-uniform: this wave holds the 32 channels of chunk kt2
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              As[row * LDS_STRIDE + (lane & 31)] = acc[i][j][r];
+            }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UB2; ++j) {
+        const int u = tid + 256 * j;
+        float *dst = Bs + (u / OCT) * LDS_STRIDE + (u % OCT) * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(rt[j][0].x, rt[j][0].y, rt[j][0].z, rt[j][0].w);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(rt[j][1].x, rt[j][1].y, rt[j][1].z, rt[j][1].w);
+      }
+      __syncthreads();
+      if (kt2 + 1 < nk2) load_w3(kt2 + 1);
+      if (kt2 + 1 == nk2) {  // the K-loop accumulators are dead now: their registers take the other row blocks
+#pragma unroll
+        for (int i = 1; i < TM; ++i) fetch_res(i);
+      }
+#pragma unroll
+      for (int o = 0; o < OCT; ++o) {
+        float4 af[TM], bf[TN2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a_frag + i * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) bf[j] = *reinterpret_cast<const float4 *>(b2_frag + j * 32 * LDS_STRIDE + o * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = s == 0 ? af[i].x : (s == 1 ? af[i].y : (s == 2 ? af[i].z : af[i].w));
+#pragma unroll
+            for (int j = 0; j < TN2; ++j) {
+              const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
+              acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc3[i][j], 0, 0, 0);
+            }
+          }
+      }
+    }
+    DBG_T(4);
+    // epilogue over TAIL_N channels: bias, residual, activation (arithmetic of Epilogue::finish, common.h); the
+    // combination is chosen once per workgroup, rows beyond M are masked in the last pixel tile only
+    {
+      float cb[TN2];
+#pragma unroll
+      for (int j = 0; j < TN2; ++j) cb[j] = p.tail_bias[col + 32 * j];
+      const uint32_t lane_off = (uint32_t)(lrow * TAIL_N + col) * 4u;
+      char *yb = reinterpret_cast<char *>(p.y + (size_t)(m0 + wm * TM * 32) * TAIL_N);
+      auto emit = [&](auto KIND, auto WHOLE) {
+        constexpr int KD = decltype(KIND)::value;  // 0-2: act2 none/relu/leaky, no residual; 3-5: same after the residual
+        constexpr bool WH = decltype(WHOLE)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = i * 32 + (r & 3) + 8 * (r >> 2);
+            if (!WH && k >= rows_left) continue;
+            char *yrow = yb + (size_t)k * (TAIL_N * 4);
+#pragma unroll
+            for (int j = 0; j < TN2; ++j) {
+              float v = acc3[i][j][r] + cb[j];
+              if constexpr (KD >= 3) v = v + rv[i][r][j];
+              if constexpr (KD % 3 == 1) v = v > 0.0f ? v : 0.0f;
+              if constexpr (KD % 3 == 2) v = v > 0.0f ? v : v * 0.01f;
+              *reinterpret_cast<float *>(yrow + lane_off + 128 * j) = v;
+            }
+          }
+      };
+      using std::integral_constant;
+      const int kind = (has_res ? 3 : 0) + (p.act2 == AIVC_ACT_RELU ? 1 : (p.act2 == AIVC_ACT_LEAKY ? 2 : 0));
+      auto emit_k = [&](auto WHOLE) {
+        switch (kind) {
+          case 0: emit(integral_constant<int, 0>{}, WHOLE); break;
+          case 1: emit(integral_constant<int, 1>{}, WHOLE); break;
+          case 2: emit(integral_constant<int, 2>{}, WHOLE); break;
+          case 3: emit(integral_constant<int, 3>{}, WHOLE); break;
+          case 4: emit(integral_constant<int, 4>{}, WHOLE); break;
+          default: emit(integral_constant<int, 5>{}, WHOLE); break;
+        }
+      };
+      if (whole) emit_k(integral_constant<bool, true>{});
+      else emit_k(integral_constant<bool, false>{});
+    }
+    DBG_T(6);
+    DBG_T(5);
+    return;
+  }
+
   DBG_T(4);
   // ---- lean epilogue for whole tiles ------------------------------------------------------------
   // Every instruction a wave issues costs the matrix pipe ~4.4 cycles (measured: dummy VALU or SALU
@@ -523,6 +692,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8 ? 2 : 1)) void conv_mfma_kernel(
           default: emit(integral_constant<int, 6>{}, integral_constant<bool, false>{}); break;
         }
       }
+      DBG_T(6);
+      DBG_T(5);
       return;
     }
   }
@@ -647,7 +818,7 @@ extern "C" __attribute__((visibility("default"))) int aivc_dbg_dump(unsigned lon
 }
 #endif
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false>
 static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   MfmaArgs a;
@@ -659,8 +830,8 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   a.gx = (a.M + BM - 1) / BM;
   a.gy = (p.c_out + BN - 1) / BN;
   dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
-  const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK>), grid, dim3(256), lds, s, a);
+  const size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
@@ -748,7 +919,16 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
   }
 }
 
+// fused 1x1 tail: a conv with c_out = 64 (one 128x64 tile owns every channel of its pixels), TAIL_N tail channels,
+// bias on both, cheap activations
+bool conv2d_mfma_tail_supported(const aivc_conv_params &p) {
+  return p.mode == AIVC_MODE_CONV && !p.gdn && !p.mul && p.c_out == 64 && p.tail_c_out == TAIL_N && p.c_in % BK == 0 &&
+         p.bias && p.tail_bias && p.tail_w && p.act1 != AIVC_ACT_SIGMOID && p.act2 != AIVC_ACT_SIGMOID &&
+         conv2d_mfma_supported(p);
+}
+
 int conv2d_mfma_variant(const aivc_conv_params &p) {
+  if (p.tail_c_out) return 190;
   const int mode = p.mode == AIVC_MODE_TCONV ? 1 : (p.mode == AIVC_MODE_CONV ? 0 : 2);
   return 100 + 10 * mode + pick_tile(p) + (p.gdn ? 50 : 0);
 }
@@ -767,7 +947,10 @@ bool conv2d_mfma_supported(const aivc_conv_params &p) {
 }
 
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
-
+  if (p.tail_c_out) {
+    if (!conv2d_mfma_tail_supported(p)) return AIVC_ERR_UNSUPPORTED;
+    return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true>(p, s);
+  }
   switch (p.mode) {
     case AIVC_MODE_CONV: return launch_mode<AIVC_MODE_CONV>(p, s);
     case AIVC_MODE_TCONV: return launch_mode<AIVC_MODE_TCONV>(p, s);

@@ -19,8 +19,8 @@ class AttentionResBlock(nn.Module):
 
     def forward_nhwc(self, x):
         h = run_conv(self.layers[0], x, 0, act1=abi.ACT_LEAKY)
-        h = run_conv(self.layers[3], h, 1, act1=abi.ACT_LEAKY)
-        return run_conv(self.layers[5], h, 0, res=x, act2=abi.ACT_LEAKY)
+        # 3x3 conv and the closing 1x1 in one launch: the nb_ft/2-wide intermediate stays on the chip
+        return run_conv(self.layers[3], h, 1, act1=abi.ACT_LEAKY, tail=self.layers[5], res=x, act2=abi.ACT_LEAKY)
 
     def forward(self, x):
         return ops.to_nchw_view(self.forward_nhwc(ops.to_nhwc(x)))

@@ -53,11 +53,18 @@ def packed_conv(conv, c_store, device, cmap=None):
     return cached(conv, ('w', c_store, str(device), None if cmap is None else tuple(cmap)), params, build)
 
 
-def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=None, gdn=None):
+def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=None, gdn=None, tail=None):
     """x NHWC -> NHWC through one aivc_conv2d launch for a torch Conv2d / ConvTranspose2d.
-    gdn: optional GDN module applied to the conv output (fused into the epilogue when possible)."""
+    gdn: optional GDN module applied to the conv output (fused into the epilogue when possible).
+    tail: optional 1x1 Conv2d applied to act1(conv(x)) in the same launch when possible; res / act2 then
+    belong to the tail."""
     c_store = (x.shape[-1] + 3) // 4 * 4
     w, b = packed_conv(conv, c_store, x.device, getattr(x, '_aivc_cmap', None))
+    if tail is not None:
+        if gdn is not None or mul is not None or isinstance(conv, ConvTranspose2d) or _sq(tail.kernel_size) != 1:
+            raise NotImplementedError('fused tail: a plain Conv2d followed by a 1x1 Conv2d')
+        w3, b3 = packed_conv(tail, (conv.out_channels + 3) // 4 * 4, x.device, None)
+        return ops.conv2d(x, w, b, stride=_sq(conv.stride), pad=pad, act1=act1, act2=act2, res=res, tail=(w3, b3))
     g = None
     if gdn is not None:
         if gdn.beta.shape[0] % 4:  # exotic channel count: padded stand-alone path

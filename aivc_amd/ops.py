@@ -95,11 +95,15 @@ def pack_weight(w, c_store=None, transposed=False):
 
 
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
-           res=None, algo=abi.ALGO_AUTO, gdn=None):
+           res=None, algo=abi.ALGO_AUTO, gdn=None, tail=None):
     """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h).
     gdn = (beta_eff, gamma_eff, inverse) fuses the (inverse) GDN into the conv epilogue when the
     kernels can (all channels of a pixel in one tile), else it is issued as a second launch --
-    bit-identical either way."""
+    bit-identical either way.
+    tail = (w3 [co2,1,1,co], b3): a 1x1 conv applied to act1(conv + bias) in the same launch when the kernels
+    can, else as a second launch (bit-identical); res / act2 then belong to the tail and y is [n,ho,wo,co2]."""
+    if tail is not None:
+        return _conv2d_tail(x, w_ohwi, bias, stride, pad, act1, act2, res, algo, tail)
     x = _dev(x, torch.float32, 'x')
     n, h, w_, c = x.shape
     cmap = getattr(x, '_aivc_cmap', None)
@@ -147,6 +151,41 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     call('aivc_conv2d', C.byref(p), _stream())
     e1.record()
     PROFILE.append((variant, flops, e0, e1, (mode, k, stride, c_real, co, n, h, w_, gdn is not None)))
+    return y
+
+
+def _conv2d_tail(x, w_ohwi, bias, stride, pad, act1, act2, res, algo, tail):
+    from ._lib import load
+    w3, b3 = tail
+    x = _dev(x, torch.float32, 'x')
+    w_ohwi = _dev(w_ohwi, torch.float32, 'weight')
+    w3 = _dev(w3, torch.float32, 'tail weight')
+    n, h, w_, c = x.shape
+    co, k, _, cw = w_ohwi.shape
+    co2 = w3.shape[0]
+    fused = c % 4 == 0 and cw == c and tuple(w3.shape) == (co2, 1, 1, co) and bias is not None and b3 is not None
+    if fused:
+        ho, wo = abi.conv_out_size(abi.MODE_CONV, h, w_, k, stride, pad)
+        y = torch.empty((n, ho, wo, co2), dtype=torch.float32, device=x.device)
+        bias, b3, res = _dev(bias, torch.float32, 'bias'), _dev(b3, torch.float32, 'tail bias'), _dev(res, torch.float32, 'res')
+        if res is not None and tuple(res.shape) != tuple(y.shape):
+            raise AivcNativeError('conv2d: res shape %s != output shape %s' % (tuple(res.shape), tuple(y.shape)))
+        p = abi.ConvParams(abi.MODE_CONV, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, 0,
+                           _p(x), _p(w_ohwi), _p(bias), None, _p(res), _p(y), None, None, _p(w3), _p(b3), co2, 0)
+        variant = load()['aivc_conv2d_variant'](C.byref(p))
+        fused = variant >= 0
+    if not fused:  # two launches, same arithmetic
+        t = conv2d(x, w_ohwi, bias, stride=stride, pad=pad, act1=act1, algo=algo)
+        return conv2d(t, w3, b3, res=res, act2=act2, algo=algo)
+    if PROFILE is None:
+        call('aivc_conv2d', C.byref(p), _stream())
+        return y
+    flops = 2.0 * (k * k * c * co + co * co2) * n * ho * wo
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call('aivc_conv2d', C.byref(p), _stream())
+    e1.record()
+    PROFILE.append((variant, flops, e0, e1, (abi.MODE_CONV, k, stride, c, co, n, h, w_, False)))
     return y
 
 

@@ -49,6 +49,8 @@ def variant_name(v):
         return 'thin_tconv_kernel'
     if v == 2:
         return 'thin_mfma_kernel'
+    if v == 190:
+        return 'conv_mfma<conv,128x64+tail1x1>'
     c = v - 100
     fused = c >= 50
     c -= 50 if fused else 0

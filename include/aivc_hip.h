@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 4 */
+int aivc_abi_version(void); /* currently 5 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -108,6 +108,15 @@ typedef struct aivc_conv_params {
   float *y;          /* [n][h_out][w_out][c_out] */
   const float *gdn_beta;  /* [c_out]         effective (re-parameterised) beta,  when gdn != 0 */
   const float *gdn_gamma; /* [c_out][c_out]  effective gamma [i][j],             when gdn != 0 */
+  /* Optional fused tail (CONV mode, no gdn): a 1x1 convolution applied to t = act1(acc + bias) in the same launch,
+   *   y[.., i] = act2( sum_j (AIVC_K_ORDER) t_j * tail_w[i][j] + tail_bias[i]  (+ res) ),   y is [n][h_out][w_out][tail_c_out]
+   * -- bit identical to this conv followed by a 1x1 CONV launch with the same epilogue (the bottleneck blocks of the
+   * attention module, src/layers/misc/attention.py:22-42: the c_out-channel intermediate never leaves the chip).
+   * mul must be NULL; res / act2 / y then refer to the tail's output.  tail_c_out == 0: no tail. */
+  const float *tail_w;    /* [tail_c_out][c_out] */
+  const float *tail_bias; /* [tail_c_out] or NULL */
+  int32_t tail_c_out;
+  int32_t reserved2;
 } aivc_conv_params;
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
@@ -115,14 +124,15 @@ typedef struct aivc_conv_params {
  *                     v_i = gdn == 1 ? v_i / sqrtf(s_i) : v_i * sqrtf(s_i)
  *                   -- bit identical to a CONV launch followed by a GDN/IGDN-mode launch];
  *                  v = act1(v);  if (mul) v = mul * v;  if (res) v = v + res;  v = act2(v).
- * A fused-gdn request the kernels cannot honour (all output channels of a pixel must sit in one
- * workgroup tile: c_out of 64 or 128 on the MFMA path) returns AIVC_ERR_UNSUPPORTED; callers then
- * issue the two launches (aivc_conv2d_variant tells in advance). */
+ * A fused-gdn or fused-tail request the kernels cannot honour (all output channels of a pixel must sit in one
+ * workgroup tile: c_out of 64 or 128 on the MFMA path; tail: c_out 64 -> tail_c_out 128, c_in % 32 == 0) returns
+ * AIVC_ERR_UNSUPPORTED; callers then issue the two launches (aivc_conv2d_variant tells in advance). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
 /* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,
  * 1 = thin-output VALU kernel (transposed conv to 3 / 6 channels), otherwise 100 + 10 * template-mode (0 conv, 1 tconv, 2 gdn) + tile id (0: 128x128, 1: 64x64,
- * 2: 256x64, 3: 128x32).  Negative = error code.  Used by bench.py to attribute launch times. */
+ * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail.
+ * Negative = error code.  Used by bench.py to attribute launch times and by callers to ask whether a fusion is available. */
 int aivc_conv2d_variant(const aivc_conv_params *p);
 
 /* GDN re-parameterisation, done once per layer instead of once per call:

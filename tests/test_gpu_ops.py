@@ -281,6 +281,62 @@ def test_fused_gdn_bit_exact(case, oracle, cuda):
     eq(got, two)
 
 
+@pytest.mark.parametrize('case', [
+    # k, stride, cin, c_mid, c_tail, n, h, w, act1, act2, res
+    (3, 1, 64, 64, 128, 2, 16, 32, abi.ACT_LEAKY, abi.ACT_LEAKY, True),   # whole 128-pixel tiles (the bottleneck block)
+    (3, 1, 64, 64, 128, 2, 17, 19, abi.ACT_LEAKY, abi.ACT_LEAKY, True),   # ragged last tile
+    (3, 1, 64, 64, 128, 1, 9, 5, abi.ACT_RELU, abi.ACT_NONE, True),       # a single partial tile
+    (3, 1, 64, 64, 128, 2, 13, 21, abi.ACT_NONE, abi.ACT_RELU, False),
+    (5, 2, 32, 64, 128, 2, 31, 27, abi.ACT_LEAKY, abi.ACT_NONE, False),
+    (1, 1, 128, 64, 128, 3, 11, 23, abi.ACT_RELU, abi.ACT_LEAKY, True),
+    (3, 1, 64, 64, 64, 2, 9, 9, abi.ACT_LEAKY, abi.ACT_LEAKY, True),      # not fusable (tail width): two launches
+    (3, 1, 8, 12, 24, 2, 9, 9, abi.ACT_LEAKY, abi.ACT_LEAKY, True),       # not fusable (narrow): two launches
+    (3, 1, 12, 6, 12, 1, 7, 9, abi.ACT_LEAKY, abi.ACT_LEAKY, True),       # intermediate width not a multiple of 4
+])
+def test_fused_tail_bit_exact(case, oracle, cuda):
+    """conv + activation + 1x1 conv (+ residual, activation) in one launch == the oracle's two convolutions"""
+    from aivc_amd import ops
+    k, s, ci, cm, ct, n, h, w, a1, a2, use_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, ci), dtype=np.float32)
+    wt = (rng.standard_normal((cm, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)
+    b1 = rng.standard_normal(cm, dtype=np.float32)
+    cm4 = (cm + 3) // 4 * 4
+    w3 = np.zeros((ct, 1, 1, cm4), dtype=np.float32)
+    w3[..., :cm] = rng.standard_normal((ct, 1, 1, cm), dtype=np.float32) / np.sqrt(cm)
+    b3 = rng.standard_normal(ct, dtype=np.float32)
+    ho, wo = abi.conv_out_size(abi.MODE_CONV, h, w, k, s, k // 2)
+    res = rng.standard_normal((n, ho, wo, ct), dtype=np.float32) if use_res else None
+    t = oracle.conv2d(x, wt, b1, stride=s, pad=k // 2, act1=a1)
+    if cm4 != cm:
+        t = np.concatenate([t, np.zeros(t.shape[:3] + (cm4 - cm,), np.float32)], axis=-1)
+    want = oracle.conv2d(t, w3, b3, res=res, act2=a2)
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b1, cuda), stride=s, pad=k // 2, act1=a1, act2=a2,
+                     res=None if res is None else T(res, cuda), tail=(T(w3, cuda), T(b3, cuda)))
+    eq(got, want)
+
+
+def test_fused_tail_is_one_launch(cuda):
+    """the bottleneck-block shape takes the fused kernel (variant 190), others are declined by the library"""
+    import ctypes as C
+    from aivc_amd._lib import load
+    x = torch.zeros((1, 16, 16, 64), device=cuda)
+    w = torch.zeros((64, 3, 3, 64), device=cuda)
+    b = torch.zeros(64, device=cuda)
+    y = torch.zeros((1, 16, 16, 128), device=cuda)
+    w3 = torch.zeros((128, 1, 1, 64), device=cuda)
+    b3 = torch.zeros(128, device=cuda)
+    ptr = lambda t: t.data_ptr()
+    p = abi.ConvParams(abi.MODE_CONV, 3, 1, 1, 1, 16, 16, 64, 16, 16, 64, abi.ACT_LEAKY, abi.ACT_LEAKY, abi.ALGO_AUTO, 0, 0,
+                       ptr(x), ptr(w), ptr(b), None, None, ptr(y), None, None, ptr(w3), ptr(b3), 128, 0)
+    assert load()['aivc_conv2d_variant'](C.byref(p)) == 190
+    p.tail_c_out = 64
+    assert load()['aivc_conv2d_variant'](C.byref(p)) < 0
+    p.tail_c_out = 128
+    p.algo = abi.ALGO_DIRECT
+    assert load()['aivc_conv2d_variant'](C.byref(p)) < 0
+
+
 @pytest.mark.parametrize('h,w', [(9, 13), (16, 32), (35, 1030)])
 def test_pack_images_bit_exact(h, w, cuda, oracle):
     """aivc_pack_images (padded multi-image input of the first convs) == oracle twin == per-image conversion"""

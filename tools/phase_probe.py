@@ -20,12 +20,20 @@ def main():
     g = None
     if os.environ.get('FUSE_GDN'):
         g = (torch.rand(co, device=dev) + 0.5, torch.rand(co, co, device=dev) * 0.01, False)
+    kw = dict(gdn=g)
+    if os.environ.get('TAIL'):  # fused 1x1 tail (the attention module's bottleneck block): 64 -> 128 + residual
+        ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+        kw = dict(tail=(torch.randn(128, 1, 1, co, device=dev) * 0.1, torch.rand(128, device=dev)), act1=abi.ACT_LEAKY,
+                  act2=abi.ACT_LEAKY, res=torch.randn(nb, ho, wo, 128, device=dev))
+    if os.environ.get('RES'):  # residual + relu epilogue (the residual blocks)
+        ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+        kw.update(res=torch.randn(nb, ho, wo, co, device=dev), act2=abi.ACT_NONE if g else abi.ACT_RELU)
     for _ in range(3):
-        ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g)
+        ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g)
+    ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, **kw)
     e1.record()
     torch.cuda.synchronize()
     lib = ctypes.CDLL(_lib.LIB_PATH)
@@ -56,7 +64,7 @@ def main():
     cu0 = cu[order[0]]
     sel = [i for i in order if cu[i] == cu0]
     print('CU %d (xcc %d) hosted %d blocks:' % (cu0 & 0xff, cu0 >> 8, len(sel)))
-    for i in sel[:16]:
+    for i in sel[:int(os.environ.get('ROWS', '16'))]:
         print('   blk %5d  start %8.1f us  end %8.1f us  pro %6d loop %7d gdn %6d epi %6d' % (i, start[i], end[i], pro[i], loop[i], gdn[i], epi[i]))
     ncu = len(set(cu.tolist()))
     print('distinct CUs', ncu, ' blocks/CU min %d max %d' % (np.bincount(np.unique(cu, return_inverse=True)[1]).min(), np.bincount(np.unique(cu, return_inverse=True)[1]).max()))
