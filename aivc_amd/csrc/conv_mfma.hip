@@ -40,6 +40,9 @@ struct MfmaArgs {
   uint32_t cin_magic;  // ceil(2^32 / c_in): k / c_in == (k * magic) >> 32 for k < 2^16
   uint32_t w_magic, h_magic;  // floor(2^32 / w_in), floor(2^32 / h_in): quotient low by at most one
   int gx, gy;                  // pixel tiles, c_out tiles (the grid is 1-D: gx x gy x parity classes)
+#ifdef AIVC_EXP_STAGGER
+  int stagger, first_round;
+#endif
 };
 
 constexpr int BK = 32;
@@ -75,6 +78,12 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
 #endif
   float *As = smem;
   float *Bs = smem + BM * LDS_STRIDE;
+#ifdef AIVC_EXP_STAGGER
+  if (a.stagger > 0 && blockIdx.x < (uint32_t)a.first_round) {
+    const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_ID.WAVE_ID
+    for (uint32_t i = 0; i < slot * (uint32_t)a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   const aivc_conv_params &p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -830,6 +839,13 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   a.gx = (a.M + BM - 1) / BM;
   a.gy = (p.c_out + BN - 1) / BN;
   dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
+#ifdef AIVC_EXP_STAGGER
+  {
+    const char *e = getenv("AIVC_STAGGER"), *f = getenv("AIVC_FIRST_ROUND");
+    a.stagger = e ? atoi(e) : 0;
+    a.first_round = f ? atoi(f) : 512;
+  }
+#endif
   const size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");

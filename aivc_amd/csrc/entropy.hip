@@ -285,20 +285,152 @@ struct BitWin {
 constexpr int DEC_D = 16;      // window prefetch depth (symbols): LDS ring of DEC_D slots
 constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
 
-// t = (span * e) >> 16 with span = hl + 1 (up to 2^32): e * hl + e < 2^48, exact in one v_mad_u64_u32
+// t = (span * e) >> 16 with span = hl + 1 (up to 2^32): e * hl + e < 2^48, exact in ONE v_mad_u64_u32 (written out:
+// the compiler turns the C expression into a 33-bit (hl + 1) * e, five instructions)
 __device__ __forceinline__ uint32_t scaled(uint32_t e, uint32_t hl) {
-  return (uint32_t)(((uint64_t)e * (uint64_t)hl + (uint64_t)e) >> 16);
+  uint64_t r, carry;
+  const uint64_t e64 = e;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(e), "s"(hl), "v"(e64));
+  return (uint32_t)(r >> 16);
 }
 
-// LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS): no register, invisible to
-// the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at the next use of ANY
-// load result in this branchy loop, i.e. for the load it has just issued: measured 0.33 us per symbol, most of it
-// that wait).  Completion is counted by hand: one DMA per symbol, in order, `s_waitcnt vmcnt(DEC_D - 1)` before
-// the slot is read.  M0 (the LDS destination base) is written in the statement that uses it.
-__device__ __forceinline__ void window_dma(const uint16_t *gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+// LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS, zero-extended): no
+// register, invisible to the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at
+// the next use of ANY load result in this branchy loop, i.e. for the load it has just issued: measured 0.33 us per
+// symbol, most of it that wait).  Completion is counted by hand: one DMA per symbol, in order,
+// `s_waitcnt vmcnt(DEC_D - 1)` before the slot is read.  Address = uniform row base + per-lane 32-bit byte offset;
+// M0 (the LDS destination base) is written in the statement that uses it (nothing else in these kernels touches M0:
+// gfx9 LDS instructions do not need it).
+__device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// One stream, one wavefront.  PLANE: a CDF row serves `plane` consecutive symbols (factorised prior of z), else one
+// row per symbol.  Written for instruction count (the chain is serial by format): ~50 instructions per symbol on
+// the common path -- window read, two subtractions, one mad + shift, compare + popcount, the DMA of the window
+// DEC_D - 1 symbols ahead with its offset bump (add + min: parked on the last row, no counter), two readlanes, the
+// interval update, and renormalisation only when a leading bit is final (skipped otherwise: at < 1 bit per
+// symbol most symbols shift nothing).
+template <bool PLANE>
+__device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes, const uint16_t *__restrict__ rows,
+                                              const aivc_rc_stream &st, uint16_t *__restrict__ sym, uint32_t *ring,
+                                              const int lane) {
+  BitWin bw;
+  bw.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
+  bw.n_words = (st.in_len + 3u) / 4u;
+  bw.tail_bytes = st.in_len & 3u;
+  bw.lane = lane;
+  bw.init();
+  uint32_t low = 0, high = 0xFFFFFFFFu;
+  const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
+  const uint32_t n_sym = st.n_sym, plane = st.plane;
+  const uint32_t n_rows = PLANE ? (n_sym + plane - 1u) / plane : n_sym;
+  const uint16_t *base = rows + st.row_off * AIVC_CDF_ROW;
+  auto row_of = [&](uint32_t i) -> const uint16_t * { return base + (uint64_t)(PLANE ? i / plane : i) * AIVC_CDF_ROW; };
+  // prefetcher: per-lane byte offset of its window entry in the row of the symbol being fetched (host side: a
+  // stream's rows span < 4 GiB)
+  uint32_t voff = (uint32_t)(DEC_WIN0 + lane) * 2u;
+  const uint32_t vlast = voff + (n_rows - 1u) * (uint32_t)(AIVC_CDF_ROW * 2);
+  uint32_t pf_slot = 0, pf_in_plane = 0;
+  auto prefetch = [&]() {
+    window_dma(base, voff, ring_base + pf_slot);
+    pf_slot = (pf_slot + 256u) & (DEC_D * 256u - 1u);
+    uint32_t step = (uint32_t)(AIVC_CDF_ROW * 2);
+    if (PLANE) {
+      ++pf_in_plane;
+      const bool wrap = pf_in_plane == plane;
+      step = wrap ? step : 0u;
+      pf_in_plane = wrap ? 0u : pf_in_plane;
+    }
+    voff = min(voff + step, vlast);
+  };
+#pragma unroll 1
+  for (uint32_t i = 0; i < DEC_D; ++i) prefetch();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 1) : "memory");
+  uint32_t ew_next = ring[lane];  // window of symbol 0
+  uint32_t rd = 64u + (uint32_t)lane;
+
+  uint32_t mysym = 0;
+#pragma unroll 1
+  for (uint32_t first = 0; first < n_sym; first += 64u) {
+    const uint32_t cnt = min(64u, n_sym - first);
+#pragma unroll 1
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t ew = ew_next;
+      // window of the next symbol (its DMA was issued DEC_D - 1 symbols ago): read now, used in the next
+      // iteration, so the LDS latency hides behind this symbol's arithmetic
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 2) : "memory");
+      ew_next = ring[rd];
+      rd = (rd + 64u) & (DEC_D * 64u - 1u);
+      const uint32_t hl = high - low;  // span - 1
+      const uint32_t d = bw.value() - low;
+      uint32_t m, t_lo, t_hi;
+      // fast path: entries are strictly increasing, so the lanes with t <= d form a prefix
+      const uint32_t tw = scaled(ew, hl);
+      const uint32_t cw = (uint32_t)__builtin_popcountll(__ballot(tw <= d));
+      prefetch();  // after the use of `ew`: its LDS read has returned before the slot is handed to the next DMA
+      if (cw - 1u < 63u) {
+        m = (uint32_t)DEC_WIN0 - 1u + cw;
+        t_lo = rl(tw, (int)cw - 1);
+        t_hi = rl(tw, (int)cw);
+      } else {
+        // symbol outside [-32, 30]: fetch and search the whole row (8 entries per lane); rare
+        uint32_t i = first + j;
+        asm volatile("" : "+s"(i));  // rare path: no running row offset kept in the loop for it
+        const uint16_t *row = row_of(i);
+        const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
+        const uint32_t nx = row[lane * 8 + 8];
+        uint32_t t[9];
+        t[0] = scaled(e.x & 0xFFFFu, hl); t[1] = scaled(e.x >> 16, hl);
+        t[2] = scaled(e.y & 0xFFFFu, hl); t[3] = scaled(e.y >> 16, hl);
+        t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
+        t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
+        t[8] = scaled(nx, hl);
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
+        m = total > 0 ? total - 1 : 0;
+        const int L = (int)(m >> 3);
+        const uint32_t idx = m & 7u;
+        uint32_t s_lo = t[0], s_hi = t[1];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+          s_lo = idx == (uint32_t)k ? t[k] : s_lo;
+          s_hi = idx == (uint32_t)k ? t[k + 1] : s_hi;
+        }
+        t_lo = rl(s_lo, L);
+        t_hi = rl(s_hi, L);
+        if (m == 511u && t_hi <= d) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign
+          m = 512u;                    // streams -- its upper bound is 2^16, i.e. t = span: high stays
+          t_lo = t_hi;
+          t_hi = hl + 1u;
+        }
+      }
+      mysym = (uint32_t)lane == j ? m : mysym;
+      // interval update (also after the last symbol: the state is dead then, reads past the payload are zeros)
+      high = low + t_hi - 1u;
+      low = low + t_lo;
+      // E1 / E2: shift out the leading bits on which low and high agree
+      const uint32_t x = low ^ high;
+      if ((int32_t)x >= 0) {
+        const uint32_t n = (uint32_t)__builtin_clz(x | 1u);
+        low <<= n;
+        high = (high << n) | ~(0xFFFFFFFFu << n);
+        bw.consume(n);
+      }
+      asm volatile("" : "+s"(high));  // keeps the test below on the scalar unit (one s_andn2 + s_bitcmp)
+      // E3: positions where (low, high) = (01.., 10..) straddle the middle
+      const uint32_t yy = low & ~high;
+      if (yy & 0x40000000u) {
+        const uint32_t m3 = (uint32_t)__builtin_clz(~(yy << 1));
+        low = (low << m3) & 0x7FFFFFFFu;
+        high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
+        bw.consume(m3);
+        bw.win ^= 0x8000000000000000ull;
+      }
+    }
+    if ((uint32_t)lane < cnt) sym[st.out_off + first + lane] = (uint16_t)mysym;
+  }
 }
 
 __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
@@ -309,118 +441,8 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
   const int lane = threadIdx.x;
   if (st.n_sym == 0) return;
   __builtin_amdgcn_s_setprio(3);  // latency-critical serial wave (see range_encode_kernel)
-  BitWin bw;
-  bw.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
-  bw.n_words = (st.in_len + 3u) / 4u;
-  bw.tail_bytes = st.in_len & 3u;
-  bw.lane = lane;
-  bw.init();
-  uint32_t low = 0, high = 0xFFFFFFFFu;
-  const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
-
-  // Row of symbol i (row addresses never depend on coder state): one per symbol, or one per `plane` symbols.
-  // The prefetcher walks a per-lane pointer: + one row per symbol (or per `plane` symbols), parked on the last row
-  // once the stream's end is reached (the DMA count stays one per symbol).
-  const uint32_t plane = st.plane;
-  auto row_of = [&](uint32_t i) -> const uint16_t * {
-    const uint64_t r = st.row_off + (plane ? (uint64_t)(i / plane) : (uint64_t)i);
-    return rows + r * AIVC_CDF_ROW;
-  };
-  const uint16_t *pf_ptr = rows + st.row_off * AIVC_CDF_ROW + DEC_WIN0 + lane;
-  uint32_t pf_i = 0, pf_in_plane = 0, pf_slot = 0;
-  auto prefetch = [&]() {
-    window_dma(pf_ptr, ring_base + pf_slot);
-    pf_slot = (pf_slot + 256u) & (DEC_D * 256u - 1u);
-    ++pf_i;
-    uint32_t step = pf_i < st.n_sym ? AIVC_CDF_ROW : 0u;
-    if (plane) {
-      ++pf_in_plane;
-      step = pf_in_plane == plane ? step : 0u;
-      pf_in_plane = pf_in_plane == plane ? 0u : pf_in_plane;
-    }
-    pf_ptr += step;
-  };
-#pragma unroll 1
-  for (uint32_t i = 0; i < DEC_D; ++i) prefetch();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 1) : "memory");
-  uint32_t ew_next = ring[lane] & 0xFFFFu;  // window of symbol 0
-  uint32_t rd_slot = 64;
-
-  uint32_t mysym = 0;
-#pragma unroll 1
-  for (uint32_t i = 0; i < st.n_sym; ++i) {
-    const uint32_t ew = ew_next;
-    // window of symbol i + 1 (its DMA was issued DEC_D - 1 symbols ago): read now, used in the next iteration, so
-    // the LDS latency hides behind this symbol's arithmetic; then refill the slot symbol i was read from
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 2) : "memory");
-    ew_next = ring[rd_slot + lane] & 0xFFFFu;
-    rd_slot = (rd_slot + 64u) & (DEC_D * 64u - 1u);
-    const uint32_t hl = high - low;  // span - 1
-    const uint32_t d = bw.value() - low;
-    uint32_t m, t_lo, t_hi;
-    // fast path: entries are strictly increasing, so the lanes with t <= d form a prefix
-    const uint32_t tw = scaled(ew, hl);
-    const uint32_t cw = (uint32_t)__builtin_popcountll(__ballot(tw <= d));
-    prefetch();  // after the use of `ew`: its LDS read has returned before the slot is handed to the next DMA
-    if (cw - 1u < 63u) {
-      m = (uint32_t)DEC_WIN0 - 1u + cw;
-      t_lo = rl(tw, (int)cw - 1);
-      t_hi = rl(tw, (int)cw);
-    } else {
-      // symbol outside [-32, 30]: fetch and search the whole row (8 entries per lane); rare
-      const uint16_t *row = row_of(i);
-      const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
-      const uint32_t nx = row[lane * 8 + 8];
-      uint32_t t[9];
-      t[0] = scaled(e.x & 0xFFFFu, hl); t[1] = scaled(e.x >> 16, hl);
-      t[2] = scaled(e.y & 0xFFFFu, hl); t[3] = scaled(e.y >> 16, hl);
-      t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
-      t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
-      t[8] = scaled(nx, hl);
-      uint32_t total = 0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
-      m = total > 0 ? total - 1 : 0;
-      const int L = (int)(m >> 3);
-      const uint32_t idx = m & 7u;
-      uint32_t s_lo = t[0], s_hi = t[1];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) {
-        s_lo = idx == (uint32_t)k ? t[k] : s_lo;
-        s_hi = idx == (uint32_t)k ? t[k + 1] : s_hi;
-      }
-      t_lo = rl(s_lo, L);
-      t_hi = rl(s_hi, L);
-      if (m == 511u && t_hi <= d) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign
-        m = 512u;                    // streams -- its upper bound is 2^16, i.e. t = span: high stays
-        t_lo = t_hi;
-        t_hi = hl + 1u;
-      }
-    }
-    if (lane == (int)(i & 63u)) mysym = m;
-    if ((i & 63u) == 63u || i == st.n_sym - 1) {
-      const uint32_t first = i & ~63u;
-      if (first + lane <= i) sym[st.out_off + first + lane] = (uint16_t)mysym;
-    }
-    if (i != st.n_sym - 1) {
-      high = low + t_hi - 1u;
-      low = low + t_lo;
-      // E1 / E2: shift out the leading bits on which low and high agree
-      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
-      low <<= n;
-      high = (high << n) | ((1u << n) - 1u);
-      bw.consume(n);
-      // E3: positions where (low, high) = (01.., 10..) straddle the middle
-      const uint32_t y = (low & ~high) << 1;
-      const uint32_t m3 = (uint32_t)__builtin_clz(~y);
-      if (m3 > 0) {
-        low = (low << m3) & 0x7FFFFFFFu;
-        high = (high << m3) | 0x80000000u | ((1u << m3) - 1u);
-        bw.consume(m3);
-        bw.win ^= 0x8000000000000000ull;
-      }
-    }
-  }
+  if (st.plane) decode_stream<true>(bytes, rows, st, sym, ring, lane);
+  else decode_stream<false>(bytes, rows, st, sym, ring, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
@@ -522,8 +544,12 @@ AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, co
   if (!bytes || !rows || !sym) return AIVC_ERR_ARG;
   if (int rc = check_batch(batch)) return rc;
   if (batch->n_streams == 0) return AIVC_OK;
-  for (int i = 0; i < batch->n_streams; ++i)
+  for (int i = 0; i < batch->n_streams; ++i) {
     if (batch->s[i].in_off % 4) return AIVC_ERR_ARG;
+    // the window prefetcher addresses a stream's rows with 32-bit byte offsets
+    const uint64_t n_rows = batch->s[i].plane ? (batch->s[i].n_sym + batch->s[i].plane - 1) / batch->s[i].plane : batch->s[i].n_sym;
+    if ((n_rows + 1) * (uint64_t)(AIVC_CDF_ROW * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(range_decode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, rows,
                      *batch, sym);
   return check_launch("range_decode");
