@@ -144,6 +144,17 @@ __global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__
 // ------------------------------------------------------------------ range encoder
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// t = (span * e) >> 16 with span = hl + 1 (up to 2^32): e * hl + e < 2^48, exact in ONE v_mad_u64_u32 (written out:
+// the compiler turns the C expression into a 33-bit (hl + 1) * e, five instructions)
+__device__ __forceinline__ uint32_t scaled(uint32_t e, uint32_t hl) {
+  uint64_t r, carry;
+  const uint64_t e64 = e;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(e), "s"(hl), "v"(e64));
+  uint32_t t = (uint32_t)(r >> 16);
+  asm("" : "+v"(t));  // the shift stays on the vector unit (one v_alignbit; moved behind a readlane it costs a second readlane)
+  return t;
+}
+
 // MSB-first bit packer.  All state is wave-uniform (SGPRs); a 32-bit word is stored (every lane issues the same
 // store: one transaction) only when it is complete -- at the ~1 bit per symbol of these latents that is one store
 // per ~30 symbols instead of one per call -- behind a wave-uniform branch.  finish() writes the partial last word.
@@ -191,35 +202,51 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
   BitSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, 0};
   uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
   const uint32_t *src = bounds + st.in_off;
+  // 64 symbols per block, lane j holds the bounds of symbol base + j.  Per symbol both interval ends
+  // t = (span * c) >> 16 are one v_mad_u64_u32 each over the whole block (lane j's result is the one read back):
+  // 6 instructions instead of the ~18 of two 33 x 16 bit products on the scalar unit.  The next block's bounds are
+  // in flight while this one is coded.
+  uint32_t nxt = lane < (int)st.n_sym ? src[lane] : 0u;
+#pragma unroll 1
   for (uint32_t base = 0; base < st.n_sym; base += 64) {
-    const uint32_t mine = (base + lane < st.n_sym) ? src[base + lane] : 0u;
-    const int cnt = (st.n_sym - base) < 64u ? (int)(st.n_sym - base) : 64;
-    for (int j = 0; j < cnt; ++j) {
-      const uint32_t b = rl(mine, j);
-      const uint32_t c_lo = b & 0xFFFFu, c_hi = b >> 16;
-      const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-      high = (low - 1u) + (uint32_t)((span * (uint64_t)c_hi) >> 16);
-      low = low + (uint32_t)((span * (uint64_t)c_lo) >> 16);
-      // E1 / E2: the n leading bits on which low and high agree are final (low < high: n <= 31)
-      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);
-      const uint32_t top = (uint32_t)(((uint64_t)low << n) >> 32);  // the n leading bits of low
-      if (pending == 0) {
-        if (n > 0) sink.put(top, n);
-      } else if (n > 0) {
-        const uint32_t b0 = low >> 31;
-        sink.put(b0, 1);
-        sink.put_run(b0 ^ 1u, pending);
-        pending = 0;
-        sink.put(top & ((1u << (n - 1)) - 1u), n - 1);
+    const uint32_t mine = nxt;
+    nxt = (base + 64u + lane < st.n_sym) ? src[base + 64u + lane] : 0u;
+    const uint32_t vlo = mine & 0xFFFFu, vhi = mine >> 16;
+    const uint32_t cnt = min(64u, st.n_sym - base);
+#pragma unroll 1
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t hl = high - low;  // span - 1
+      const uint32_t t_lo = rl(scaled(vlo, hl), (int)j), t_hi = rl(scaled(vhi, hl), (int)j);
+      high = low + t_hi - 1u;
+      low = low + t_lo;
+      // E1 / E2: the n leading bits on which low and high agree are final (low < high: n <= 31); nothing to do
+      // for the many symbols that settle no bit
+      const uint32_t x = low ^ high;
+      if ((int32_t)x >= 0) {
+        const uint32_t n = (uint32_t)__builtin_clz(x | 1u);
+        const uint32_t top = (uint32_t)(((uint64_t)low << n) >> 32);  // the n leading bits of low
+        uint32_t bits = top, nb = n;
+        if (pending != 0) {  // the first settled bit releases the pending straddle bits (its complement)
+          const uint32_t b0 = low >> 31;
+          sink.put(b0, 1);
+          sink.put_run(b0 ^ 1u, pending);
+          pending = 0;
+          nb = n - 1u;
+          bits = top & ((1u << nb) - 1u);
+        }
+        sink.put(bits, nb);
+        low <<= n;
+        high = (high << n) | ~(0xFFFFFFFFu << n);
       }
-      low <<= n;
-      high = (high << n) | ((1u << n) - 1u);
+      asm volatile("" : "+s"(high));  // keeps the test below on the scalar unit
       // E3: now low = 0..., high = 1...; every further position with (low,high) = (1,0) straddles
-      const uint32_t y = (low & ~high) << 1;
-      const uint32_t m = (uint32_t)__builtin_clz(~y);  // leading ones of y (0..31)
-      pending += m;
-      low = (low << m) & 0x7FFFFFFFu;
-      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      const uint32_t yy = low & ~high;
+      if (yy & 0x40000000u) {
+        const uint32_t m = (uint32_t)__builtin_clz(~(yy << 1));  // leading ones (1..31)
+        pending += m;
+        low = (low << m) & 0x7FFFFFFFu;
+        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      }
     }
   }
   pending += 1;
@@ -284,15 +311,6 @@ struct BitWin {
 
 constexpr int DEC_D = 16;      // window prefetch depth (symbols): LDS ring of DEC_D slots
 constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
-
-// t = (span * e) >> 16 with span = hl + 1 (up to 2^32): e * hl + e < 2^48, exact in ONE v_mad_u64_u32 (written out:
-// the compiler turns the C expression into a 33-bit (hl + 1) * e, five instructions)
-__device__ __forceinline__ uint32_t scaled(uint32_t e, uint32_t hl) {
-  uint64_t r, carry;
-  const uint64_t e64 = e;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(e), "s"(hl), "v"(e64));
-  return (uint32_t)(r >> 16);
-}
 
 // LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS, zero-extended): no
 // register, invisible to the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at
