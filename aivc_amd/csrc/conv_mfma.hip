@@ -62,7 +62,7 @@ __device__ unsigned long long aivc_dbg_t[8 * 8192];
 constexpr int TAIL_N = 128;  // output channels of the fused 1x1 tail (the bottleneck blocks: 64 -> 128)
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false>
-__global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 1))) void conv_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1)))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(!TAIL || (MODE == AIVC_MODE_CONV && !FUSE && FASTK && BN == 64 && BN % BK == 0), "fused tail: conv, c_out 64");
   constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
@@ -857,14 +857,14 @@ static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, false>(p, s);
 }
 
-// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128, 5 = 64x128
+// tile menu {BM x BN}: id 0 = 128x128, 1 = 64x64, 2 = 256x64, 3 = 128x32, 4 = 256x128, 5 = 64x128, 6 = 128x64
 static int pick_tile_auto(const aivc_conv_params &p);
 static int pick_tile(const aivc_conv_params &p) {
   // tuning aid: AIVC_FORCE_TILE=<id> overrides the choice when that tile can run the shape
   if (const char *e = getenv("AIVC_FORCE_TILE")) {
     const int t = atoi(e);
     const int bn = t == 0 || t == 4 || t == 5 ? 128 : (t == 3 ? 32 : 64);
-    if (t >= 0 && t <= 5 && (!p.gdn || (bn == p.c_out && t != 4))) return t;
+    if (t >= 0 && t <= 6 && (!p.gdn || (bn == p.c_out && t != 4))) return t;
   }
   return pick_tile_auto(p);
 }
@@ -888,6 +888,10 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   if ((p.act1 == AIVC_ACT_SIGMOID || p.act2 == AIVC_ACT_SIGMOID) && !p.gdn) return 1;
   // c_out = 64: 256x64 (four waves stacked along M, 4 accumulators each) once there are >= ~1000 such tiles and
   // the reduction is long; else the small tile (r02 sweep, tools/_tile_sweep.sh: 109 vs 107, 94 vs 91 TFLOP/s)
+  // 128x64 (id 6: 126 registers, four waves per SIMD) is ahead where the epilogue weighs most against a short or
+  // loader-heavy reduction: the image layers (c_in of 4 / 8 / 12), 1x1 and stride-2 convs (r02: 4080 vs 4232 us,
+  // 114 vs 119, 548 vs 582); transposed convs and the 3x3 stay on 256x64 / 64x64
+  if (co <= 64 && !t && M >= 65536 && (p.c_in % BK != 0 || p.ksize == 1 || p.stride == 2)) return 6;
   if (co <= 64) return (M >= 250000 && kred >= 96) ? 2 : 1;
   if (p.gdn) return (t && p.ksize == 3) ? 5 : 0;  // BN must equal c_out = 128
   auto score = [&](int bm, int bn, int slots, double base) {
@@ -921,6 +925,7 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
         case 1: return launch_cfg<MODE, 2, 2, 1, 1, true>(p, s);
         case 2: return launch_cfg<MODE, 4, 1, 2, 2, true>(p, s);
         case 5: return launch_cfg<MODE, 2, 2, 1, 2, true>(p, s);
+        case 6: return launch_cfg<MODE, 2, 2, 2, 1, true>(p, s);
         default: return launch_cfg<MODE, 4, 1, 1, 1, true>(p, s);
       }
     }
@@ -931,6 +936,7 @@ static int launch_mode(const aivc_conv_params &p, hipStream_t s) {
     case 2: return launch_cfg<MODE, 4, 1, 2, 2, false>(p, s);
     case 4: return launch_cfg<MODE, 4, 1, 2, 4, false>(p, s);
     case 5: return launch_cfg<MODE, 2, 2, 1, 2, false>(p, s);
+    case 6: return launch_cfg<MODE, 2, 2, 2, 1, false>(p, s);
     default: return launch_cfg<MODE, 4, 1, 1, 1, false>(p, s);
   }
 }

@@ -37,7 +37,7 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0         # same guide: HBM3E 8 TB/s (spec; 6.3 TB/s is the measured copy ceiling)
-_TILES = {0: '128x128', 1: '64x64', 2: '256x64', 3: '128x32', 4: '256x128', 5: '64x128'}
+_TILES = {0: '128x128', 1: '64x64', 2: '256x64', 3: '128x32', 4: '256x128', 5: '64x128', 6: '128x64'}
 _MODES = {0: 'conv', 1: 'tconv', 2: 'gdn'}
 
 

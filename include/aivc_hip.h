@@ -131,7 +131,7 @@ int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
 /* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,
  * 1 = thin-output VALU kernel (transposed conv to 3 / 6 channels), otherwise 100 + 10 * template-mode (0 conv, 1 tconv, 2 gdn) + tile id (0: 128x128, 1: 64x64,
- * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail.
+ * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128, 6: 128x64) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail.
  * Negative = error code.  Used by bench.py to attribute launch times and by callers to ask whether a fusion is available. */
 int aivc_conv2d_variant(const aivc_conv_params *p);
 
