@@ -91,8 +91,9 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
 
 
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
-           res=None, gdn=None, cmap=None):
+           res=None, gdn=None, cmap=None, tail=None):
     """gdn = (beta_eff, gamma_eff, inverse): (inverse) GDN fused after the bias.
+    tail = (w3 [co2,1,1,co], b3): fused 1x1 tail (include/aivc_hip.h); res / act2 then belong to it, y has co2 channels.
     cmap: stored position of every input channel (default: the first ones, zero padding behind).  The
     accumulation order of the contract is defined on STORED positions (groups of 8 in AIVC_K_ORDER), so an
     input the codec stores as 3-channel images each padded to 4 must be laid out the same way here."""
@@ -116,7 +117,13 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
             [w_ohwi, np.zeros(w_ohwi.shape[:3] + (c - w_ohwi.shape[3],), np.float32)], axis=3))
     co, k = w_ohwi.shape[0], w_ohwi.shape[1]
     ho, wo = abi.conv_out_size(mode, h, w_, k, stride, pad)
-    y = np.empty((n, ho, wo, co), np.float32)
+    w3 = b3 = None
+    co2 = 0
+    if tail is not None:
+        w3, b3 = _f32(tail[0]), (None if tail[1] is None else _f32(tail[1]))
+        co2 = w3.shape[0]
+        assert w3.shape[1:] == (1, 1, co), 'tail weight must be [co2, 1, 1, co]'
+    y = np.empty((n, ho, wo, co2 or co), np.float32)
     bias = None if bias is None else _f32(bias)
     mul = None if mul is None else _f32(mul)
     res = None if res is None else _f32(res)
@@ -125,7 +132,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     if gdn is not None:
         gb, gg, gflag = _f32(gdn[0]), _f32(gdn[1]), (2 if gdn[2] else 1)
     p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0, gflag, 0,
-                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg))
+                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg), _p(w3), _p(b3), co2, 0)
     _chk(lib()['aivc_conv2d'](C.byref(p), None), 'aivc_conv2d')
     return y
 

@@ -311,6 +311,8 @@ def test_fused_tail_bit_exact(case, oracle, cuda):
     if cm4 != cm:
         t = np.concatenate([t, np.zeros(t.shape[:3] + (cm4 - cm,), np.float32)], axis=-1)
     want = oracle.conv2d(t, w3, b3, res=res, act2=a2)
+    if cm4 == cm:  # the oracle's own fused twin
+        np.testing.assert_array_equal(oracle.conv2d(x, wt, b1, stride=s, pad=k // 2, act1=a1, act2=a2, res=res, tail=(w3, b3)), want)
     got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b1, cuda), stride=s, pad=k // 2, act1=a1, act2=a2,
                      res=None if res is None else T(res, cuda), tail=(T(w3, cuda), T(b3, cuda)))
     eq(got, want)
