@@ -6,9 +6,10 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 AIVC_OK = 0
+ERR_UNSUPPORTED = -2
 ERRORS = {0: 'AIVC_OK', -1: 'AIVC_ERR_ARG', -2: 'AIVC_ERR_UNSUPPORTED', -3: 'AIVC_ERR_LAUNCH',
           -4: 'AIVC_ERR_WORKSPACE'}
 
@@ -85,6 +86,7 @@ PROTOTYPES = {
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_pack_images': [C.POINTER(ImageSrc), _i32, _i32, _i32, _i32, _f],
+    'aivc_conv_images': [C.POINTER(ImageSrc), _i32, C.POINTER(ConvParams)],
     'aivc_frame_to_yuv420': [_f, _i32, _i32, _i32, _i32, _f, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f],
     'aivc_downsample2x': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'aivc_warp_blend': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],

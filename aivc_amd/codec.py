@@ -59,10 +59,11 @@ class FrameCodec:
 
     @staticmethod
     def _images(parts, h, w, device):
-        """Concatenate 3-channel images, each padded to 4 stored channels, in ONE kernel (aivc_pack_images):
+        """Concatenation of 3-channel images, each padded to 4 stored channels (layout of aivc_pack_images):
         parts are plane dicts (converted), NHWC [n,h,w,4] float tensors (first 3 channels copied) or
         None (zeros).  The result carries the stored position of every real channel for the first conv."""
-        return ops.pack_images(parts, h, w, device)  # one launch, contiguous stores (no memset, no per-image pass)
+        # lazy: the first conv reads the sources itself (aivc_conv_images); packed only if a layer cannot
+        return ops.ImageStack(parts, h, w, device)
 
     def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
         """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts

@@ -19,7 +19,7 @@ int check_launch(const char *what) {
 }
 }  // namespace aivc
 
-AIVC_EXPORT int aivc_abi_version(void) { return 5; }
+AIVC_EXPORT int aivc_abi_version(void) { return 6; }
 AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
 
 static int validate_conv(const aivc_conv_params *p) {
@@ -67,6 +67,20 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin_variant(*p);
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
   return 0;
+}
+
+AIVC_EXPORT int aivc_conv_images(const aivc_image_src *src, int32_t n_img, const aivc_conv_params *p, aivc_stream_t stream) {
+  if (!p || !p->w || !p->y || !src || n_img < 1 || n_img > AIVC_MAX_IMAGES) return AIVC_ERR_ARG;
+  if (p->n <= 0 || p->h_in <= 0 || p->w_in <= 0) return AIVC_ERR_ARG;
+  for (int i = 0; i < n_img; ++i) {
+    if (src[i].y && (!src[i].u || !src[i].v)) return AIVC_ERR_ARG;
+    if (!src[i].y && src[i].f && src[i].f_channels < 3) return AIVC_ERR_ARG;
+  }
+  if (!aivc::conv_images_supported(src, n_img, *p)) return AIVC_ERR_UNSUPPORTED;
+  if (p->h_out != (p->h_in + 2 * p->pad - p->ksize) / p->stride + 1 || p->w_out != (p->w_in + 2 * p->pad - p->ksize) / p->stride + 1)
+    return AIVC_ERR_ARG;
+  if (p->gdn && (p->gdn < 0 || p->gdn > 2 || !p->gdn_beta || !p->gdn_gamma)) return AIVC_ERR_ARG;
+  return aivc::conv_images(src, n_img, *p, aivc::to_stream(stream));
 }
 
 AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {

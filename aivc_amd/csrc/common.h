@@ -56,6 +56,8 @@ int conv2d_mfma(const aivc_conv_params &p, hipStream_t s);  // AIVC_ERR_UNSUPPOR
 bool conv2d_mfma_supported(const aivc_conv_params &p);
 bool conv2d_mfma_tail_supported(const aivc_conv_params &p);
 int conv2d_mfma_variant(const aivc_conv_params &p);  // 100 + 10*mode + tile id (+50 fused gdn); 190 fused 1x1 tail
+bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p);
+int conv_images(const aivc_image_src *src, int n_img, const aivc_conv_params &p, hipStream_t s);  // conv_images.hip
 bool conv2d_thin_supported(const aivc_conv_params &p);
 int conv2d_thin(const aivc_conv_params &p, hipStream_t s);  // c_out of 3 / 6 (transposed conv): 16x16x4 MFMA or VALU kernel
 int conv2d_thin_variant(const aivc_conv_params &p);          // 2 = thin_mfma_kernel, 1 = thin_tconv_kernel

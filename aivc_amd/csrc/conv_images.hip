@@ -1,0 +1,343 @@
+// conv_images.hip -- the first layer of the analysis transforms: 5x5 stride-2 replicate-padded convolution to 64
+// channels (+ bias, + fused GDN) over the concatenation of up to three 3-channel images, read straight from their
+// sources (8-bit 4:2:0 planes or float NHWC).  Bit identical to aivc_pack_images followed by aivc_conv2d on the
+// packed [n][h][w][4 * n_img] tensor (AIVC_CONV_SPARSE4), whose 48-byte-per-pixel round trip through HBM it removes.
+//
+// Why a kernel of its own: with 4 / 8 / 12 stored input channels a 32-wide K-tile of the generic implicit GEMM
+// straddles several kernel taps, so its loader decodes (tap, channel) per 16-byte load and the layer ran at half
+// the rate of the others.  Here the reduction is short enough (K = 100 / 200 / 300) to keep ALL of it on chip:
+//   - a workgroup owns 4 x 32 output pixels; the 11 x 67 input patch is converted once (k / 255.0f from a table,
+//     chroma by nearest neighbour, replicate padding = clamped coordinates) into LDS, split by column parity and
+//     image so that the 32 pixels of a wavefront read 512 contiguous bytes for every (tap, image);
+//   - the whole weight matrix [64][K] sits in LDS beside it (row stride chosen conflict-free for ds_read_b128);
+//   - a workgroup walks 8 consecutive tiles: weights, gamma fragments (registers), bias / beta are fetched once, the
+//     raw samples of the next tile are in flight during the matrix work of the current one;
+//   - per tile 13 / 25 / 38 octets of v_mfma_f32_32x32x2_f32 with both operands read from LDS, no staging, no
+//     barrier inside; the zero fourth channel of every image is never multiplied (an exact no-op);
+//   - reduction order = the contract of the conv family (include/aivc_hip.h): kk = tap * c_in + 4 * image + c in
+//     groups of 8, inside a group in AIVC_K_ORDER -- octet o is quads 2 o (lanes 0-31) and 2 o + 1 (lanes 32-63);
+//   - fused GDN as in conv_mfma.hip (second MFMA GEMM over the squares); the squares of a wavefront's 32 pixels
+//     go through LDS rows only that wavefront touches, gamma comes from registers: no barrier, no shared staging.
+// roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic FLOPs 2 * 25 * 3 n_img * 64 (+ 2 * 64 * 64 GDN) per output pixel.
+// Measured (r02, 16 x 1080p): 2.1 / 2.8 / 5.2 ms for 1 / 2 / 3 images against 1.9 / 2.8 / 3.7 ms of the generic kernel
+// on the packed tensor plus 0.2 / 0.4 / 0.6 ms to pack it: at par for one and two images (and 0.5 / 1 GB less HBM
+// traffic and memory per call), slower for three (113 KB of LDS: one workgroup per CU) -- the codec sends those
+// down the pack + conv path.  The layer is bounded by its epilogue (64 square roots and divisions per pixel against
+// 75 / 150 / 225 multiply-adds per output), not by the matrix pipe (50 % busy).
+#include "common.h"
+
+namespace aivc {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct ImgArgs {
+  aivc_image_src src[AIVC_MAX_IMAGES];
+  const float *w, *bias, *gdn_beta, *gdn_gamma;
+  float *y;
+  int n, h, w_in, ho, wo, gdn, act1;
+  int tiles_x, tiles_y;
+};
+
+constexpr int IC_TH = 4, IC_TW = 32;    // output pixels per workgroup: one row of 32 per wavefront
+constexpr int IC_PR = 2 * IC_TH + 3;    // patch rows
+constexpr int IC_PC = 2 * IC_TW + 3;    // patch columns
+constexpr int IC_HALF = IC_TW + 2;      // columns of one parity
+constexpr int IC_PLANE = IC_HALF * 4;   // floats of one (row, parity, image) plane
+constexpr int IC_CO = 64;
+constexpr int IC_LS = 36;               // LDS row stride of the GDN tiles (32 + 4)
+
+// weight row stride in floats: = 36 / 12 / 44 (mod 64), so the 16 lanes of a ds_read_b128 phase hit 16 distinct
+// bank quads
+template <int NIMG>
+constexpr int ic_wstride() { return NIMG == 2 ? 204 : 100 * NIMG; }
+template <int NIMG>
+constexpr int ic_region_floats() {  // patch, later the squares of the GDN (128 rows x 36)
+  const int patch = IC_PR * 2 * NIMG * IC_PLANE, gdn = 128 * IC_LS;
+  return patch > gdn ? patch : gdn;
+}
+template <int NIMG>
+constexpr int ic_lds_floats() { return IC_CO * ic_wstride<NIMG>() + ic_region_floats<NIMG>(); }
+
+constexpr int IC_TPW = 8;  // consecutive tiles per workgroup: weights and gamma are fetched once for all of them
+
+template <int NIMG>
+__global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
+  constexpr int NQ = 25 * NIMG;        // quads (tap, image) of the reduction
+  constexpr int NO = (NQ + 1) / 2;     // octets
+  constexpr int WS = ic_wstride<NIMG>();
+  constexpr int K = 100 * NIMG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float lut[256];
+  float *Wl = smem;
+  float *patch = smem + IC_CO * WS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, hh = lane >> 5;
+  lut[tid] = (float)tid / 255.0f;
+  const int H = a.h, W = a.w_in, hc = (H + 1) / 2, wc = (W + 1) / 2;
+  const uint32_t ntiles = (uint32_t)a.n * (uint32_t)a.tiles_y * (uint32_t)a.tiles_x;
+  const uint32_t t_first = blockIdx.x * (uint32_t)IC_TPW;
+  const uint32_t t_end = min(t_first + (uint32_t)IC_TPW, ntiles);
+
+  // ---- once per workgroup: weights -> LDS (float4 = one quad of one output channel), GDN operands -> registers
+  {
+    constexpr int WU = (IC_CO * NQ + 255) / 256;
+    float4 wreg[WU];
+#pragma unroll
+    for (int i = 0; i < WU; ++i) {
+      const int u = tid + 256 * i;
+      const int uc = u < IC_CO * NQ ? u : 0;
+      const int co = uc / NQ, q = uc - co * NQ;
+      wreg[i] = *reinterpret_cast<const float4 *>(a.w + (size_t)co * K + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < WU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < IC_CO * NQ) {
+        const int co = u / NQ, q = u - co * NQ;
+        *reinterpret_cast<float4 *>(Wl + co * WS + 4 * q) = make_float4(wreg[i].x, wreg[i].y, wreg[i].z, wreg[i].w);
+      }
+    }
+  }
+  const bool gdn = a.gdn != 0;
+  // B fragments of the GDN GEMM (gamma[i][k], i = 32 j + p, k = 32 c + 8 o + 4 hh ..): 16 float4 per lane, kept
+  // for all tiles -- the second GEMM then needs no shared staging, no barrier and no global latency per tile
+  float4 greg[2][4][2];
+  float cbias[2], cbeta[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    cbias[j] = a.bias ? a.bias[32 * j + p] : 0.0f;
+    cbeta[j] = gdn ? a.gdn_beta[32 * j + p] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        greg[c][o][j] = gdn ? *reinterpret_cast<const float4 *>(a.gdn_gamma + (size_t)(32 * j + p) * IC_CO + 32 * c + 8 * o + 4 * hh)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- patch staging units of this thread: LDS destination and source kind do not depend on the tile
+  constexpr int PU = (IC_PR * IC_PC * NIMG + 255) / 256;
+  int pdst[PU], ppr[PU], ppc[PU], pimg[PU];  // LDS float offset (< 0: none; bit 30: byte samples), patch row / column, image
+#pragma unroll
+  for (int i = 0; i < PU; ++i) {
+    const int u = tid + 256 * i;
+    const bool live = u < IC_PR * IC_PC * NIMG;
+    const int uc = live ? u : 0;
+    const int img = uc % NIMG, r2 = uc / NIMG;
+    const int pc = r2 % IC_PC, pr = r2 / IC_PC;
+    int dst = live ? (((pr * 2 + (pc & 1)) * NIMG + img) * IC_HALF + (pc >> 1)) * 4 : -1;
+    if (live && a.src[img].y) dst |= 1 << 30;
+    pdst[i] = dst;
+    ppr[i] = pr;
+    ppc[i] = pc;
+    pimg[i] = img;
+  }
+  uint32_t raw[PU][3];  // bytes (8-bit sources) or float bits of the NEXT tile's samples
+  auto tile_of = [&](uint32_t t, int &b, int &oy0, int &ox0) {
+    const uint32_t tx = t % (uint32_t)a.tiles_x;
+    t /= (uint32_t)a.tiles_x;
+    oy0 = (int)(t % (uint32_t)a.tiles_y) * IC_TH;
+    b = (int)(t / (uint32_t)a.tiles_y);
+    ox0 = (int)tx * IC_TW;
+  };
+  auto fetch = [&](uint32_t t) {  // every global load of the tile is issued before any is used
+    int b, oy0, ox0;
+    tile_of(t, b, oy0, ox0);
+#pragma unroll
+    for (int i = 0; i < PU; ++i) {
+      const int iy = min(max(2 * oy0 - 2 + ppr[i], 0), H - 1), ix = min(max(2 * ox0 - 2 + ppc[i], 0), W - 1);
+      const aivc_image_src &s = a.src[pimg[i]];
+      raw[i][0] = raw[i][1] = raw[i][2] = 0u;
+      if (s.y) {
+        raw[i][0] = s.y[((size_t)b * H + iy) * W + ix];
+        raw[i][1] = s.u[((size_t)b * hc + (iy >> 1)) * wc + (ix >> 1)];
+        raw[i][2] = s.v[((size_t)b * hc + (iy >> 1)) * wc + (ix >> 1)];
+      } else if (s.f) {
+        const float *f = s.f + (((size_t)b * H + iy) * W + ix) * s.f_channels;
+        raw[i][0] = __float_as_uint(f[0]);
+        raw[i][1] = __float_as_uint(f[1]);
+        raw[i][2] = __float_as_uint(f[2]);
+      }
+    }
+  };
+  if (t_first < t_end) fetch(t_first);
+
+  const float *abase = patch + (2 * wave * 2 * NIMG * IC_HALF + p) * 4;
+  const float *bbase = Wl + p * WS;
+  float *As = patch;  // the squares of the GDN reuse the patch: rows of wave w are written and read by wave w only
+  const float *a_frag = As + (wave * 32 + p) * IC_LS + hh * 4;
+
+  for (uint32_t t = t_first; t < t_end; ++t) {
+    int b, oy0, ox0;
+    tile_of(t, b, oy0, ox0);
+    __syncthreads();  // lut / weights (first tile); everybody is done with the previous tile's squares
+#pragma unroll
+    for (int i = 0; i < PU; ++i) {
+      if (pdst[i] >= 0) {
+        const bool bytes = (pdst[i] >> 30) & 1;
+        float4 v;
+        v.x = bytes ? lut[raw[i][0] & 255u] : __uint_as_float(raw[i][0]);
+        v.y = bytes ? lut[raw[i][1] & 255u] : __uint_as_float(raw[i][1]);
+        v.z = bytes ? lut[raw[i][2] & 255u] : __uint_as_float(raw[i][2]);
+        v.w = 0.0f;
+        *reinterpret_cast<float4 *>(patch + (pdst[i] & 0x3FFFFFFF)) = v;
+      }
+    }
+    __syncthreads();
+    if (t + 1 < t_end) fetch(t + 1);  // in flight during this tile's matrix work
+
+    // ---- main loop: operands straight from LDS --------------------------------------------------
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      // compile-time offsets of quads 2 o (lanes 0-31) and 2 o + 1 (lanes 32-63)
+      constexpr auto offa = [](int q) {
+        const int tap = q / NIMG, img = q % NIMG, ky = tap / 5, kx = tap % 5;
+        return (((ky * 2 + (kx & 1)) * NIMG + img) * IC_HALF + (kx >> 1)) * 4;
+      };
+      const bool odd_tail = 2 * o + 1 >= NQ;  // the last octet of an odd quad count has no second half
+      const int a0 = offa(2 * o), a1 = odd_tail ? a0 : offa(2 * o + 1);
+      const int b0 = 8 * o, b1 = odd_tail ? b0 : 8 * o + 4;
+      const float *ap = abase + a0 + hh * (a1 - a0);
+      const float *bp = bbase + b0 + hh * (b1 - b0);
+      float4 af = *reinterpret_cast<const float4 *>(ap);
+      float4 bf0 = *reinterpret_cast<const float4 *>(bp);
+      float4 bf1 = *reinterpret_cast<const float4 *>(bp + 32 * WS);
+      if (odd_tail && hh) {  // zero operands for the missing quad (what a zero-padded K tile multiplies)
+        af = make_float4(0.f, 0.f, 0.f, 0.f);
+        bf0 = af;
+        bf1 = af;
+      }
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf1.z, acc[1], 0, 0, 0);
+      // .w: the zero fourth channel of the image -- fmaf(0, w, acc) = acc, not issued
+    }
+
+    // ---- bias, fused (inverse) GDN ------------------------------------------------------------
+    if (a.bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] + cbias[j];
+    }
+    floatx16 acc2[2];
+    if (gdn) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+      __syncthreads();  // every wavefront is done reading the patch
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float xv = acc[c][r];
+          asm volatile("" : "+v"(xv));
+          As[(wave * 32 + m) * IC_LS + p] = xv * xv;
+        }
+        // rows of this wavefront only: the LDS executes a wavefront's accesses in order, no barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const float4 af = *reinterpret_cast<const float4 *>(a_frag + 8 * o);
+          const float4 g0 = greg[c][o][0], g1 = greg[c][o][1];
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, g0.x, acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, g1.x, acc2[1], 0, 0, 0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, g0.y, acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, g1.y, acc2[1], 0, 0, 0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, g0.z, acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, g1.z, acc2[1], 0, 0, 0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, g0.w, acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, g1.w, acc2[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+
+    // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes ----------------------
+    const int oy = oy0 + wave;
+    if (oy < a.ho) {
+      float *yrow = a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO + p;
+      const int act1 = a.act1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float v = acc[j][r];
+          if (gdn) {
+            const float nrm = __builtin_sqrtf(acc2[j][r] + cbeta[j]);
+            v = a.gdn == 2 ? v * nrm : v / nrm;
+          } else {
+            const float neg = act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v);
+            v = v > 0.0f ? v : neg;
+          }
+          if (ox0 + m < a.wo) yrow[(size_t)m * IC_CO + 32 * j] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NIMG>
+static int launch_images(const ImgArgs &a, hipStream_t s) {
+  const size_t lds = (size_t)ic_lds_floats<NIMG>() * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_images_kernel<NIMG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return AIVC_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const unsigned ntiles = (unsigned)a.n * (unsigned)a.tiles_y * (unsigned)a.tiles_x;
+  const unsigned grid = (ntiles + IC_TPW - 1) / IC_TPW;
+  hipLaunchKernelGGL(conv_images_kernel<NIMG>, dim3(grid), dim3(256), lds, s, a);
+  return check_launch("conv_images");
+}
+
+bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p) {
+  if (!src || n_img < 1 || n_img > AIVC_MAX_IMAGES) return false;
+  if (p.mode != AIVC_MODE_CONV || p.ksize != 5 || p.stride != 2 || p.pad != 2 || p.c_out != IC_CO || p.c_in != 4 * n_img) return false;
+  if (p.mul || p.res || p.act2 != AIVC_ACT_NONE || p.tail_c_out) return false;
+  if (p.gdn ? p.act1 != AIVC_ACT_NONE : p.act1 == AIVC_ACT_SIGMOID) return false;
+  if ((uint64_t)p.n * ((p.h_out + IC_TH - 1) / IC_TH) * ((p.w_out + IC_TW - 1) / IC_TW) >= 0x7FFFFFFFull) return false;
+  return true;
+}
+
+int conv_images(const aivc_image_src *src, int n_img, const aivc_conv_params &p, hipStream_t s) {
+  ImgArgs a;
+  for (int i = 0; i < AIVC_MAX_IMAGES; ++i) a.src[i] = aivc_image_src{nullptr, nullptr, nullptr, nullptr, 0, 0};
+  for (int i = 0; i < n_img; ++i) a.src[i] = src[i];
+  a.w = p.w;
+  a.bias = p.bias;
+  a.gdn_beta = p.gdn_beta;
+  a.gdn_gamma = p.gdn_gamma;
+  a.y = p.y;
+  a.n = p.n;
+  a.h = p.h_in;
+  a.w_in = p.w_in;
+  a.ho = p.h_out;
+  a.wo = p.w_out;
+  a.gdn = p.gdn;
+  a.act1 = p.act1;
+  a.tiles_x = (p.w_out + IC_TW - 1) / IC_TW;
+  a.tiles_y = (p.h_out + IC_TH - 1) / IC_TH;
+  switch (n_img) {
+    case 1: return launch_images<1>(a, s);
+    case 2: return launch_images<2>(a, s);
+    default: return launch_images<3>(a, s);
+  }
+}
+
+}  // namespace aivc

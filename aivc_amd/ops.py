@@ -6,6 +6,7 @@ tensors.  Feature maps are NHWC fp32 ([n, h, w, c], contiguous).  CPU tensors ar
 product has no CPU execution path (the CPU restatement lives in oracle/ and is test-only).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -45,6 +46,8 @@ def _stream():
 def _dev(t, dtype=None, name='tensor'):
     if t is None:
         return None
+    if isinstance(t, ImageStack):  # used as anything but the input of the first conv: materialise
+        t = t.tensor()
     if not t.is_cuda:
         raise AivcNativeError('aivc_amd.ops: %s is on %s; the HIP path needs CUDA tensors '
                               '(no CPU fallback)' % (name, t.device))
@@ -102,6 +105,18 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     bit-identical either way.
     tail = (w3 [co2,1,1,co], b3): a 1x1 conv applied to act1(conv + bias) in the same launch when the kernels
     can, else as a second launch (bit-identical); res / act2 then belong to the tail and y is [n,ho,wo,co2]."""
+    if not isinstance(x, ImageStack) and getattr(x, '_aivc_cmap', None) == (0, 1, 2) and x.dim() == 4 and x.shape[-1] == 4 \
+            and mode == abi.MODE_CONV and tail is None:
+        st = ImageStack([x], x.shape[1], x.shape[2], x.device)  # a single float image (the prediction fed to g_a_ref)
+        st._packed = x
+        x = st
+    if isinstance(x, ImageStack):
+        y = None
+        if tail is None and mode == abi.MODE_CONV:
+            y = _conv_images(x, w_ohwi, bias, stride, pad, act1, act2, mul, res, algo, gdn)
+        if y is not None:
+            return y
+        x = x.tensor()
     if tail is not None:
         return _conv2d_tail(x, w_ohwi, bias, stride, pad, act1, act2, res, algo, tail)
     x = _dev(x, torch.float32, 'x')
@@ -235,6 +250,86 @@ def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
                   lambda: call('aivc_yuv420u8_to_444' if u8 else 'aivc_yuv420_to_444', _p(y), _p(u), _p(v), n, h, w,
                                _p(out), out.shape[-1], c_off, zero_pad, _stream()))
     return out
+
+
+_CONV_IMAGES_MAX = int(os.environ.get('AIVC_CONV_IMAGES_MAX', '2'))  # tuning aid: 0 disables aivc_conv_images
+
+
+class ImageStack:
+    """The concatenation of up to 3 images (each stored as 3 real channels + a zero) as the first analysis conv sees
+    it -- NOT materialised: conv2d() runs aivc_conv_images straight on the sources when the kernel covers the layer,
+    and falls back to tensor() (aivc_pack_images) otherwise.  Quacks like the packed NHWC tensor for the few
+    attributes the layers read (shape, device, _aivc_cmap)."""
+
+    def __init__(self, parts, h, w, device):
+        self.parts, self.h, self.w, self.device = list(parts), h, w, device
+        self.n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
+        self.shape = (self.n, h, w, 4 * len(self.parts))
+        self.dtype = torch.float32
+        self._aivc_cmap = tuple(4 * i + c for i in range(len(self.parts)) for c in range(3))
+        self._packed = None
+
+    def sources(self):
+        """(ImageSrc array, tensors to keep alive)"""
+        arr = (abi.ImageSrc * abi.MAX_IMAGES)()
+        keep = []
+        for i, p in enumerate(self.parts):
+            if isinstance(p, dict):
+                y, u, v = (_dev(p[k], torch.uint8, k) for k in 'yuv')
+                keep += [y, u, v]
+                arr[i].y, arr[i].u, arr[i].v = y.data_ptr(), u.data_ptr(), v.data_ptr()
+            elif p is not None:
+                f = _dev(p, torch.float32, 'image')
+                keep.append(f)
+                arr[i].f, arr[i].f_channels = f.data_ptr(), f.shape[-1]
+        return arr, keep
+
+    def tensor(self):
+        if self._packed is None:
+            self._packed = pack_images(self.parts, self.h, self.w, self.device)
+        return self._packed
+
+
+def _conv_images(x, w_ohwi, bias, stride, pad, act1, act2, mul, res, algo, gdn):
+    """aivc_conv_images on an ImageStack; None when the library declines the layer (caller packs and convolves)"""
+    from ._lib import load
+    if mul is not None or res is not None or act2 or algo != abi.ALGO_AUTO:
+        return None
+    # three images (K = 300, 113 KB of LDS: one workgroup per CU) measured slower than pack + generic conv
+    # (5.2 vs ~4.3 ms at 16 x 1080p), one and two images at par with the conv alone and without the packed tensor
+    if len(x.parts) > _CONV_IMAGES_MAX:
+        return None
+    w_ohwi = _dev(w_ohwi, torch.float32, 'weight')
+    co, k, _, cw = w_ohwi.shape
+    n, h, w_, c = x.shape
+    if cw != c:
+        return None
+    ho, wo = abi.conv_out_size(abi.MODE_CONV, h, w_, k, stride, pad)
+    y = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
+    bias = _dev(bias, torch.float32, 'bias')
+    g_beta = g_gamma = None
+    gflag = 0
+    if gdn is not None:
+        g_beta, g_gamma, gflag = gdn[0], gdn[1], (2 if gdn[2] else 1)
+    p = abi.ConvParams(abi.MODE_CONV, k, stride, pad, n, h, w_, c, ho, wo, co, act1, 0, algo, gflag, abi.CONV_SPARSE4,
+                       None, _p(w_ohwi), _p(bias), None, None, _p(y), _p(g_beta), _p(g_gamma))
+    arr, keep = x.sources()
+    e0 = e1 = None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = load()['aivc_conv_images'](arr, len(x.parts), C.byref(p), _stream())
+    if rc == abi.ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        raise AivcNativeError('aivc_conv_images failed (%d)' % rc)
+    if PROFILE is not None:
+        e1.record()
+        c_real = len(x._aivc_cmap)
+        flops = 2.0 * k * k * c_real * co * n * ho * wo + (2.0 * co * co * n * ho * wo if gdn is not None else 0.0)
+        PROFILE.append((191, flops, e0, e1, (abi.MODE_CONV, k, stride, c_real, co, n, h, w_, gdn is not None)))
+    del keep
+    return y
 
 
 def pack_images(parts, h, w, device):

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 5 */
+int aivc_abi_version(void); /* currently 6 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -131,7 +131,7 @@ int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
 /* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,
  * 1 = thin-output VALU kernel (transposed conv to 3 / 6 channels), otherwise 100 + 10 * template-mode (0 conv, 1 tconv, 2 gdn) + tile id (0: 128x128, 1: 64x64,
- * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128, 6: 128x64) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail.
+ * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128, 6: 128x64) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail (191: aivc_conv_images).
  * Negative = error code.  Used by bench.py to attribute launch times and by callers to ask whether a fusion is available. */
 int aivc_conv2d_variant(const aivc_conv_params *p);
 
@@ -178,6 +178,16 @@ typedef struct {
 } aivc_image_src;
 int aivc_pack_images(const aivc_image_src *src, int32_t n_img, int32_t n, int32_t h, int32_t w, float *out,
                      aivc_stream_t stream);
+
+/* The first layer of the analysis transforms in one launch: aivc_conv2d(p) over the tensor aivc_pack_images(src, n_img)
+ * would produce -- without producing it.  p->x is ignored (may be NULL), p->c_in must be 4 * n_img, p->n / h_in / w_in
+ * are the image batch and size, p->w is packed for the 4-channels-per-image layout ([c_out][5][5][4 * n_img], zero
+ * columns for the fourth channels).  Bit identical to the two calls.  Implemented for what the codec uses
+ * (CustomConvLayer(5, stride 2) to 64 channels with GDN or a cheap activation: ksize 5, stride 2, pad 2, c_out 64, bias /
+ * fused gdn / act1 in {none, leaky, relu}, no mul / res / act2 / tail); anything else returns AIVC_ERR_UNSUPPORTED and the
+ * caller issues the two calls.  Replaces InputLayer + torch.cat + CustomConvLayer at the head of g_a / g_a_ref
+ * (src/layers/ae/ae_layers.py:27-35, src/layers/misc/custom_conv_layers.py:129-180). */
+int aivc_conv_images(const aivc_image_src *src, int32_t n_img, const aivc_conv_params *p, aivc_stream_t stream);
 
 /* Reconstruction tail of Decoder.decode: x_hat = x[:, :h, :w, :3] (+ skip), OutputLayer
  * (U,V = bilinear x0.5, align_corners=False = 2x2 mean), replicate-pad U,V to ceil(h/2) x

@@ -202,6 +202,35 @@ def pack_images(parts, h, w):
     return out
 
 
+def conv_images(parts, h, w, w_ohwi, bias=None, act1=0, gdn=None, stride=2, pad=2):
+    """oracle twin of aivc_conv_images: conv2d over pack_images(parts) without the caller packing"""
+    n = next(p['y'].shape[0] if isinstance(p, dict) else p.shape[0] for p in parts if p is not None)
+    arr = (abi.ImageSrc * abi.MAX_IMAGES)()
+    keep = []
+    for i, p in enumerate(parts):
+        if isinstance(p, dict):
+            y, u, v = (np.ascontiguousarray(p[k], np.uint8) for k in 'yuv')
+            keep += [y, u, v]
+            arr[i].y, arr[i].u, arr[i].v = y.ctypes.data, u.ctypes.data, v.ctypes.data
+        elif p is not None:
+            f = _f32(p)
+            keep.append(f)
+            arr[i].f, arr[i].f_channels = f.ctypes.data, f.shape[-1]
+    w_ohwi = _f32(w_ohwi)
+    co, k = w_ohwi.shape[0], w_ohwi.shape[1]
+    ho, wo = abi.conv_out_size(abi.MODE_CONV, h, w, k, stride, pad)
+    y_out = np.empty((n, ho, wo, co), np.float32)
+    bias = None if bias is None else _f32(bias)
+    gb = gg = None
+    gflag = 0
+    if gdn is not None:
+        gb, gg, gflag = _f32(gdn[0]), _f32(gdn[1]), (2 if gdn[2] else 1)
+    p = abi.ConvParams(abi.MODE_CONV, k, stride, pad, n, h, w, 4 * len(parts), ho, wo, co, act1, 0, 0, gflag, 0,
+                       None, _p(w_ohwi), _p(bias), None, None, _p(y_out), _p(gb), _p(gg))
+    _chk(lib()['aivc_conv_images'](arr, len(parts), C.byref(p), None), 'aivc_conv_images')
+    return y_out
+
+
 def frame_to_yuv420(x, h, w, skip=None):
     """returns (y, u, v) fp32 8-bit levels and (y8, u8, v8) bytes"""
     x = _f32(x)

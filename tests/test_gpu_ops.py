@@ -339,6 +339,63 @@ def test_fused_tail_is_one_launch(cuda):
     assert load()['aivc_conv2d_variant'](C.byref(p)) < 0
 
 
+@pytest.mark.parametrize('h,w,n', [(9, 13, 2), (16, 128, 1), (35, 131, 2), (64, 64, 3)])
+@pytest.mark.parametrize('use_gdn', [True, False])
+def test_conv_images_bit_exact(h, w, n, use_gdn, cuda, oracle, monkeypatch):
+    """aivc_conv_images (first analysis layer straight from the image sources) == oracle conv over the packed tensor
+    == the HIP pack + conv pair, for 1 / 2 / 3 images, 8-bit 4:2:0 and float sources, ragged tiles"""
+    import ctypes as C
+    from aivc_amd import ops
+    from aivc_amd._lib import load
+    monkeypatch.setattr(ops, '_CONV_IMAGES_MAX', 3)  # the codec sends 3-image stacks down the pack + conv path (faster)
+    rng = np.random.default_rng(h * 1000 + w + (7 if use_gdn else 0))
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+
+    def planes():
+        return {'y': rng.integers(0, 256, (n, h, w), dtype=np.uint8), 'u': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8),
+                'v': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8)}
+    a, b = planes(), planes()
+    f = rng.standard_normal((n, h, w, 4)).astype(np.float32)
+    f[..., 3] = 0.0
+    dev = lambda p: {k: torch.from_numpy(p[k]).to(cuda) for k in 'yuv'}
+    for parts_np in ([a], [f], [a, b], [a, f], [a, b, a], [f, a, None]):
+        ni = len(parts_np)
+        wt = np.zeros((64, 5, 5, 4 * ni), np.float32)
+        for i in range(ni):
+            wt[..., 4 * i:4 * i + 3] = rng.standard_normal((64, 5, 5, 3)).astype(np.float32) / np.sqrt(75 * ni)
+        bias = rng.standard_normal(64, dtype=np.float32)
+        g = None
+        if use_gdn:
+            g = ((np.abs(rng.standard_normal(64)) + 0.2).astype(np.float32),
+                 (np.abs(rng.standard_normal((64, 64))) * 0.05).astype(np.float32), False)
+        act1 = 0 if use_gdn else abi.ACT_LEAKY
+        packed = oracle.pack_images(parts_np, h, w)
+        want = oracle.conv2d(packed, wt, bias, stride=2, pad=2, act1=act1, gdn=g)
+        np.testing.assert_array_equal(oracle.conv_images(parts_np, h, w, wt, bias, act1=act1, gdn=g), want)
+        parts_t = [dev(p) if isinstance(p, dict) else (None if p is None else torch.from_numpy(p).to(cuda)) for p in parts_np]
+        gt = None if g is None else (T(g[0], cuda), T(g[1], cuda), False)
+        before = load()['aivc_abi_version']()
+        stack = ops.ImageStack(parts_t, h, w, cuda)
+        got = ops.conv2d(stack, T(wt, cuda), T(bias, cuda), stride=2, pad=2, act1=act1, gdn=gt)
+        assert stack._packed is None, 'the fused kernel must have taken this layer (no packed tensor)'
+        eq(got, want)
+        # the two-call path it replaces
+        two = ops.conv2d(ops.pack_images(parts_t, h, w, cuda), T(wt, cuda), T(bias, cuda), stride=2, pad=2, act1=act1, gdn=gt)
+        eq(two, want)
+        assert before == abi.ABI_VERSION
+
+
+def test_conv_images_declines_other_layers(cuda):
+    """layers outside the kernel's coverage fall back to pack + conv (same result path as before)"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(5)
+    f = torch.from_numpy(rng.standard_normal((1, 12, 12, 4)).astype(np.float32)).to(cuda)
+    stack = ops.ImageStack([f], 12, 12, cuda)
+    w = torch.from_numpy(rng.standard_normal((32, 3, 3, 4)).astype(np.float32)).to(cuda)
+    y = ops.conv2d(stack, w, None, stride=1, pad=1)
+    assert stack._packed is not None and tuple(y.shape) == (1, 12, 12, 32)
+
+
 @pytest.mark.parametrize('h,w', [(9, 13), (16, 32), (35, 1030)])
 def test_pack_images_bit_exact(h, w, cuda, oracle):
     """aivc_pack_images (padded multi-image input of the first convs) == oracle twin == per-image conversion"""

@@ -38,3 +38,19 @@ def test_tail_argument_checks(oracle):
         oracle.conv2d(x, w, None, mul=np.zeros((1, 4, 4, 8), np.float32), tail=(w3, None))
     with pytest.raises(Exception):  # nor a fused gdn
         oracle.conv2d(x, w, None, gdn=(np.ones(4, np.float32), np.zeros((4, 4), np.float32), False), tail=(w3, None))
+
+
+def test_conv_images_twin_equals_pack_then_conv(oracle):
+    """aivc_conv_images_ref is by definition aivc_conv2d_ref over aivc_pack_images_ref"""
+    rng = np.random.default_rng(11)
+    n, h, w = 1, 11, 14
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    a = {'y': rng.integers(0, 256, (n, h, w), dtype=np.uint8), 'u': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8),
+         'v': rng.integers(0, 256, (n, hc, wc), dtype=np.uint8)}
+    f = rng.standard_normal((n, h, w, 3)).astype(np.float32)
+    wt = np.zeros((8, 5, 5, 8), np.float32)
+    wt[..., :3] = rng.standard_normal((8, 5, 5, 3)).astype(np.float32)
+    wt[..., 4:7] = rng.standard_normal((8, 5, 5, 3)).astype(np.float32)
+    bias = rng.standard_normal(8, dtype=np.float32)
+    want = oracle.conv2d(oracle.pack_images([a, f], h, w), wt, bias, stride=2, pad=2, act1=abi.ACT_RELU)
+    np.testing.assert_array_equal(oracle.conv_images([a, f], h, w, wt, bias, act1=abi.ACT_RELU), want)
