@@ -640,26 +640,53 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       auto emit = [&](auto KIND, auto INV) {
         constexpr int KD = decltype(KIND)::value;
         constexpr bool IV = decltype(INV)::value;
+        auto row_of = [&](int idx, int &k, uint32_t &off) {
+          k = (idx >> 4) * 32 + (idx & 3) + 8 * ((idx & 15) >> 2);
+          off = lane_off;
+          if constexpr (TCONV) {
+            uint32_t qx = qx0 + (uint32_t)k;
+            const uint32_t qw = qx - (uint32_t)W;
+            qx = qx < qw ? qx : qw;  // one wrap at most (W >= BM): the unsigned difference is huge when there is none
+            off += ((uint32_t)W - qx) * cout8;
+          }
+        };
+        // Fused GDN + residual (the closing conv of the residual blocks): rows are kept apart by scheduling barriers
+        // (registers), which made every row one dependent round trip for its residual (46 k instead of 24 k cycles
+        // per tile, tools/phase_probe.py): the residual of row idx + 4 is requested while row idx is computed.
+        constexpr int RD = (FUSE && KD >= 3 && !TCONV) ? 4 : 0;  // (transposed: the extra row offsets cost the second wave per SIMD)
+        float rq[RD ? RD : 1][TN];
+        auto load_res = [&](int idx, float (&dst)[TN]) {
+          int k;
+          uint32_t off;
+          row_of(idx, k, off);
+          const char *rrow = rb_ + (size_t)k * kstep;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
+        };
+        if constexpr (RD > 0) {
+#pragma unroll
+          for (int d = 0; d < RD; ++d) load_res(d, rq[d]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int k = i * 32 + (r & 3) + 8 * (r >> 2);
-            uint32_t off = lane_off;
-            if constexpr (TCONV) {
-              uint32_t qx = qx0 + (uint32_t)k;
-              const uint32_t qw = qx - (uint32_t)W;
-              qx = qx < qw ? qx : qw;  // one wrap at most (W >= BM): the unsigned difference is huge when there is none
-              off += ((uint32_t)W - qx) * cout8;
-            }
+            const int idx = i * 16 + r;
+            int k;
+            uint32_t off;
+            row_of(idx, k, off);
             char *yrow = yb + (size_t)k * kstep;
             const char *rrow = rb_ + (size_t)k * kstep;
             const char *xrow = xb + (size_t)k * kstep;
             float rv[TN], xv[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              if constexpr (KD >= 3) rv[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
+              if constexpr (RD > 0) rv[j] = rq[idx % RD][j];
+              else if constexpr (KD >= 3) rv[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
               if constexpr (GDN) xv[j] = *reinterpret_cast<const float *>(xrow + off + 128 * j);
+            }
+            if constexpr (RD > 0) {
+              if (idx + RD < TM * 16) load_res(idx + RD, rq[idx % RD]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
