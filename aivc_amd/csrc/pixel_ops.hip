@@ -263,6 +263,67 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(BlendArgs a) {
   }
 }
 
+// The codec's layout (references and outputs stored as 4 channels, 6 flow / mask channels): every tap is ONE 16-byte
+// gather instead of three 4-byte ones, the outputs are 16-byte stores.  Same arithmetic per channel, in the same
+// order (0 + nw * a, + ne * b, + sw * c, + se * d; out-of-frame taps are skipped, not added as zeros).
+__device__ __forceinline__ void warp_apply4(const float *img, const WarpTap &t, float &r0, float &r1, float &r2) {
+  r0 = r1 = r2 = 0.0f;
+  if (t.o00 >= 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)t.o00 * 4);
+    r0 = r0 + v.x * t.nw; r1 = r1 + v.y * t.nw; r2 = r2 + v.z * t.nw;
+  }
+  if (t.o01 >= 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)t.o01 * 4);
+    r0 = r0 + v.x * t.ne; r1 = r1 + v.y * t.ne; r2 = r2 + v.z * t.ne;
+  }
+  if (t.o10 >= 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)t.o10 * 4);
+    r0 = r0 + v.x * t.sw; r1 = r1 + v.y * t.sw; r2 = r2 + v.z * t.sw;
+  }
+  if (t.o11 >= 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)t.o11 * 4);
+    r0 = r0 + v.x * t.se; r1 = r1 + v.y * t.se; r2 = r2 + v.z * t.se;
+  }
+}
+__global__ __launch_bounds__(256) void warp_blend4_kernel(BlendArgs a) {
+  const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (size_t)a.n * a.h * a.w) return;
+  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.h), b = (int)(pix / ((size_t)a.w * a.h));
+  const float2 *m = reinterpret_cast<const float2 *>(a.mof + (((size_t)b * a.hm + r) * a.wm + q) * a.cm);
+  const float2 m01 = m[0], m23 = m[1], m45 = m[2];
+  float alpha = m01.x + 0.5f;
+  alpha = alpha < 0.0f ? 0.0f : (alpha > 1.0f ? 1.0f : alpha);
+  float beta = m01.y + 0.5f;
+  beta = beta < 0.0f ? 0.0f : (beta > 1.0f ? 1.0f : beta);
+  float vpx = m23.x, vpy = m23.y, vnx = m45.x, vny = m45.y;
+  if (a.frame_type == 1) {
+    beta = 1.0f;
+    vnx = 0.0f;
+    vny = 0.0f;
+  }
+  if (a.alpha_out) a.alpha_out[pix] = alpha;
+  if (a.beta_out) a.beta_out[pix] = beta;
+  const float *pimg = a.prev + (size_t)b * a.h * a.w * 4;
+  const float *nimg = a.next + (size_t)b * a.h * a.w * 4;
+  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, r, q);
+  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, r, q);
+  float wp[3], wn[3];
+  warp_apply4(pimg, tp, wp[0], wp[1], wp[2]);
+  warp_apply4(nimg, tn, wn[0], wn[1], wn[2]);
+  float xw[3], pr[3], sk[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float t1 = beta * wp[ch];
+    const float t2 = (1.0f - beta) * wn[ch];
+    xw[ch] = t1 + t2;
+    pr[ch] = xw[ch] * alpha;
+    sk[ch] = (1.0f - alpha) * xw[ch];
+  }
+  if (a.x_warp) reinterpret_cast<float4 *>(a.x_warp)[pix] = make_float4(xw[0], xw[1], xw[2], 0.0f);
+  if (a.pred) reinterpret_cast<float4 *>(a.pred)[pix] = make_float4(pr[0], pr[1], pr[2], 0.0f);
+  if (a.skip) reinterpret_cast<float4 *>(a.skip)[pix] = make_float4(sk[0], sk[1], sk[2], 0.0f);
+}
+
 // ---------------------------------------------------------------- latent ops
 __global__ __launch_bounds__(256) void hyper_params_kernel(const float *__restrict__ hs, int n, int hh, int wh,
                                                            int c, int h, int w, float *__restrict__ mu,
@@ -441,6 +502,12 @@ AIVC_EXPORT int aivc_warp_blend(const float *mof, int32_t hm, int32_t wm, int32_
   if (!mof || !prev || !next || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
   if (hm < h || wm < w || cm < 6 || cr < 3 || co < 3) return AIVC_ERR_ARG;
   BlendArgs a{mof, prev, next, hm, wm, cm, cr, n, h, w, frame_type, co, pred, skip, x_warp, alpha_out, beta_out};
+  auto al16 = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (cr == 4 && co == 4 && cm % 2 == 0 && (reinterpret_cast<uintptr_t>(mof) & 7u) == 0 && al16(prev) && al16(next) &&
+      al16(pred) && al16(skip) && al16(x_warp)) {
+    hipLaunchKernelGGL(warp_blend4_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), a);
+    return check_launch("warp_blend");
+  }
   hipLaunchKernelGGL(warp_blend_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), a);
   return check_launch("warp_blend");
 }

@@ -123,6 +123,16 @@ def test_warp_bit_exact(oracle, cuda):
             g = ops.warp_blend(T(mof, cuda), T(prev, cuda), T(nxt, cuda), h, w, ft, want_aux=True)
             for kk in ('pred', 'skip', 'x_warp', 'alpha', 'beta'):
                 eq(g[kk], r[kk])
+            # the general kernel (3 stored reference channels, 3 output channels, 7 mask / flow channels) against
+            # the 16-byte fast path above (4 / 4 / 8)
+            mof7 = np.ascontiguousarray(mof[..., :7])
+            r3 = oracle.warp_blend(mof7, prev[..., :3].copy(), nxt[..., :3].copy(), h, w, ft, co=3)
+            g3 = ops.warp_blend(T(mof7, cuda), T(prev[..., :3].copy(), cuda), T(nxt[..., :3].copy(), cuda), h, w, ft, co=3,
+                                want_aux=True)
+            for kk in ('pred', 'skip', 'x_warp', 'alpha', 'beta'):
+                eq(g3[kk], r3[kk])
+                if kk in ('pred', 'skip', 'x_warp'):
+                    np.testing.assert_array_equal(r3[kk], r[kk][..., :3])
 
 
 def test_latent_ops_bit_exact(oracle, cuda):
