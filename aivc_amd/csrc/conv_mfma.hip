@@ -598,6 +598,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       if (p.res != nullptr && a1 == AIVC_ACT_NONE && a2 != AIVC_ACT_SIGMOID) kind = a2 == AIVC_ACT_NONE ? 3 : (a2 == AIVC_ACT_RELU ? 4 : 5);
       if (p.res != nullptr && a1 == AIVC_ACT_LEAKY && a2 == AIVC_ACT_NONE) kind = 6;
     }
+    // 7: the attention gate x + trunk * sigmoid(conv) -- 64x64 tiles only (16 outputs per thread: sixteen inlined
+    // copies of the fp64-polynomial sigmoid fit the instruction cache, the 128 of a 128x128 tile did not)
+    if (TM * TN == 1 && p.mul != nullptr && p.res != nullptr && p.bias != nullptr && a1 == AIVC_ACT_SIGMOID && a2 == AIVC_ACT_NONE)
+      kind = 7;
     if ((FUSE || GDN) && kind != 0 && kind != 3) kind = -1;
     const bool whole = m0 + BM <= M && n0 + BN <= Cout && (!TCONV || W >= BM);
     if (whole && kind >= 0) {
@@ -636,6 +640,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       char *yb = reinterpret_cast<char *>(p.y + base_elems);
       const char *rb_ = reinterpret_cast<const char *>(p.res + base_elems);
       const char *xb = reinterpret_cast<const char *>(p.x + base_elems);
+      const char *mb_ = reinterpret_cast<const char *>(p.mul + base_elems);
       const bool inv = FUSE ? p.gdn == 2 : p.mode == AIVC_MODE_IGDN;
       auto emit = [&](auto KIND, auto INV) {
         constexpr int KD = decltype(KIND)::value;
@@ -653,8 +658,8 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
         // Fused GDN + residual (the closing conv of the residual blocks): rows are kept apart by scheduling barriers
         // (registers), which made every row one dependent round trip for its residual (46 k instead of 24 k cycles
         // per tile, tools/phase_probe.py): the residual of row idx + 4 is requested while row idx is computed.
-        constexpr int RD = (FUSE && KD >= 3 && !TCONV) ? 4 : 0;  // (transposed: the extra row offsets cost the second wave per SIMD)
-        float rq[RD ? RD : 1][TN];
+        constexpr int RD = ((FUSE && KD >= 3 && !TCONV) || KD == 7) ? 4 : 0;  // (transposed: the extra row offsets cost the second wave per SIMD)
+        float rq[RD ? RD : 1][TN], mq[KD == 7 ? RD : 1][TN];
         auto load_res = [&](int idx, float (&dst)[TN]) {
           int k;
           uint32_t off;
@@ -662,6 +667,11 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
           const char *rrow = rb_ + (size_t)k * kstep;
 #pragma unroll
           for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
+          if constexpr (KD == 7) {  // the gate's multiplicand travels with the residual
+            const char *mrow = mb_ + (size_t)k * kstep;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mq[idx % RD][j] = *reinterpret_cast<const float *>(mrow + off + 128 * j);
+          }
         };
         if constexpr (RD > 0) {
 #pragma unroll
@@ -678,9 +688,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
             char *yrow = yb + (size_t)k * kstep;
             const char *rrow = rb_ + (size_t)k * kstep;
             const char *xrow = xb + (size_t)k * kstep;
-            float rv[TN], xv[TN];
+            float rv[TN], xv[TN], mv[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+              if constexpr (KD == 7) mv[j] = mq[idx % RD][j];
               if constexpr (RD > 0) rv[j] = rq[idx % RD][j];
               else if constexpr (KD >= 3) rv[j] = *reinterpret_cast<const float *>(rrow + off + 128 * j);
               if constexpr (GDN) xv[j] = *reinterpret_cast<const float *>(xrow + off + 128 * j);
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
                   v = IV ? xv[j] * nrm : xv[j] / nrm;
                 }
               }
+              if constexpr (KD == 7) v = mv[j] * aivc_sigmoidf_det(v);
               if constexpr (KD == 1 || KD == 6) v = v > 0.0f ? v : v * 0.01f;
               if constexpr (KD == 2) v = v > 0.0f ? v : 0.0f;
               if constexpr (KD >= 3) v = v + rv[j];
@@ -725,6 +737,9 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
           case 3: emit(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
           case 4: emit(integral_constant<int, 4>{}, integral_constant<bool, false>{}); break;
           case 5: emit(integral_constant<int, 5>{}, integral_constant<bool, false>{}); break;
+          case 7:
+            if constexpr (TM * TN == 1) emit(integral_constant<int, 7>{}, integral_constant<bool, false>{});
+            break;
           default: emit(integral_constant<int, 6>{}, integral_constant<bool, false>{}); break;
         }
       }

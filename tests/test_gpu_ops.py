@@ -328,6 +328,22 @@ def test_fused_tail_bit_exact(case, oracle, cuda):
     eq(got, want)
 
 
+@pytest.mark.parametrize('n,h,w,c', [(2, 16, 32, 128), (1, 9, 11, 128), (2, 8, 8, 64)])
+def test_attention_gate_epilogue_bit_exact(n, h, w, c, oracle, cuda):
+    """x + trunk * sigmoid(conv1x1(a)) in the conv epilogue (whole 64x64 tiles take the inlined-sigmoid path, ragged ones
+    the general one): both equal the oracle"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(n * 100 + h)
+    a = rng.standard_normal((n, h, w, c), dtype=np.float32)
+    wt = (rng.standard_normal((c, 1, 1, c), dtype=np.float32) / np.sqrt(c)).astype(np.float32)
+    b = rng.standard_normal(c, dtype=np.float32)
+    trunk = rng.standard_normal((n, h, w, c), dtype=np.float32)
+    x = rng.standard_normal((n, h, w, c), dtype=np.float32)
+    want = oracle.conv2d(a, wt, b, act1=abi.ACT_SIGMOID, mul=trunk, res=x)
+    got = ops.conv2d(T(a, cuda), T(wt, cuda), T(b, cuda), act1=abi.ACT_SIGMOID, mul=T(trunk, cuda), res=T(x, cuda))
+    eq(got, want)
+
+
 def test_fused_tail_is_one_launch(cuda):
     """the bottleneck-block shape takes the fused kernel (variant 190), others are declined by the library"""
     import ctypes as C
