@@ -24,6 +24,8 @@
 // traffic and memory per call), slower for three (113 KB of LDS: one workgroup per CU) -- the codec sends those
 // down the pack + conv path.  The layer is bounded by its epilogue (64 square roots and divisions per pixel against
 // 75 / 150 / 225 multiply-adds per output), not by the matrix pipe (50 % busy).
+#include <type_traits>
+
 #include "common.h"
 
 namespace aivc {
@@ -115,23 +117,20 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
                             : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // ---- patch staging units of this thread: LDS destination and source kind do not depend on the tile
+  // ---- patch staging units of this thread (unit = one (row, column, image) sample triple).  Their decomposition is
+  // recomputed per tile from an opaque copy of the thread index: kept live across the matrix work (4 values per
+  // unit) it pushed the kernel over the 256 registers of two waves per SIMD
   constexpr int PU = (IC_PR * IC_PC * NIMG + 255) / 256;
-  int pdst[PU], ppr[PU], ppc[PU], pimg[PU];  // LDS float offset (< 0: none; bit 30: byte samples), patch row / column, image
-#pragma unroll
-  for (int i = 0; i < PU; ++i) {
-    const int u = tid + 256 * i;
+  auto unit_of = [&](int tt, int i, int &pr, int &pc, int &img, int &dst) {
+    const int u = tt + 256 * i;
     const bool live = u < IC_PR * IC_PC * NIMG;
     const int uc = live ? u : 0;
-    const int img = uc % NIMG, r2 = uc / NIMG;
-    const int pc = r2 % IC_PC, pr = r2 / IC_PC;
-    int dst = live ? (((pr * 2 + (pc & 1)) * NIMG + img) * IC_HALF + (pc >> 1)) * 4 : -1;
-    if (live && a.src[img].y) dst |= 1 << 30;
-    pdst[i] = dst;
-    ppr[i] = pr;
-    ppc[i] = pc;
-    pimg[i] = img;
-  }
+    img = uc % NIMG;
+    const int r2 = uc / NIMG;
+    pc = r2 % IC_PC;
+    pr = r2 / IC_PC;
+    dst = live ? (((pr * 2 + (pc & 1)) * NIMG + img) * IC_HALF + (pc >> 1)) * 4 : -1;  // LDS float offset, < 0: none
+  };
   uint32_t raw[PU][3];  // bytes (8-bit sources) or float bits of the NEXT tile's samples
   auto tile_of = [&](uint32_t t, int &b, int &oy0, int &ox0) {
     const uint32_t tx = t % (uint32_t)a.tiles_x;
@@ -143,10 +142,14 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
   auto fetch = [&](uint32_t t) {  // every global load of the tile is issued before any is used
     int b, oy0, ox0;
     tile_of(t, b, oy0, ox0);
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int i = 0; i < PU; ++i) {
-      const int iy = min(max(2 * oy0 - 2 + ppr[i], 0), H - 1), ix = min(max(2 * ox0 - 2 + ppc[i], 0), W - 1);
-      const aivc_image_src &s = a.src[pimg[i]];
+      int pr, pc, img, dst;
+      unit_of(tt, i, pr, pc, img, dst);
+      const int iy = min(max(2 * oy0 - 2 + pr, 0), H - 1), ix = min(max(2 * ox0 - 2 + pc, 0), W - 1);
+      const aivc_image_src &s = a.src[img];
       raw[i][0] = raw[i][1] = raw[i][2] = 0u;
       if (s.y) {
         raw[i][0] = s.y[((size_t)b * H + iy) * W + ix];
@@ -171,16 +174,22 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     int b, oy0, ox0;
     tile_of(t, b, oy0, ox0);
     __syncthreads();  // lut / weights (first tile); everybody is done with the previous tile's squares
+    {
+      int tt = tid;
+      asm volatile("" : "+v"(tt));
 #pragma unroll
-    for (int i = 0; i < PU; ++i) {
-      if (pdst[i] >= 0) {
-        const bool bytes = (pdst[i] >> 30) & 1;
-        float4 v;
-        v.x = bytes ? lut[raw[i][0] & 255u] : __uint_as_float(raw[i][0]);
-        v.y = bytes ? lut[raw[i][1] & 255u] : __uint_as_float(raw[i][1]);
-        v.z = bytes ? lut[raw[i][2] & 255u] : __uint_as_float(raw[i][2]);
-        v.w = 0.0f;
-        *reinterpret_cast<float4 *>(patch + (pdst[i] & 0x3FFFFFFF)) = v;
+      for (int i = 0; i < PU; ++i) {
+        int pr, pc, img, dst;
+        unit_of(tt, i, pr, pc, img, dst);
+        if (dst >= 0) {
+          const bool bytes = a.src[img].y != nullptr;
+          float4 v;
+          v.x = bytes ? lut[raw[i][0] & 255u] : __uint_as_float(raw[i][0]);
+          v.y = bytes ? lut[raw[i][1] & 255u] : __uint_as_float(raw[i][1]);
+          v.z = bytes ? lut[raw[i][2] & 255u] : __uint_as_float(raw[i][2]);
+          v.w = 0.0f;
+          *reinterpret_cast<float4 *>(patch + dst) = v;
+        }
       }
     }
     __syncthreads();
@@ -264,27 +273,47 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       }
     }
 
-    // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes ----------------------
+    // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes; the normalisation / activation
+    // variant and the edge masking are chosen once per tile (uniform branch), not per element
     const int oy = oy0 + wave;
     if (oy < a.ho) {
       float *yrow = a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO + p;
-      const int act1 = a.act1;
+      const int cols = a.wo - ox0;  // output columns of this tile that exist (>= 1)
+      auto emit = [&](auto MODE, auto WHOLE) {
+        constexpr int MD = decltype(MODE)::value;  // 0 / 1 / 2: no GDN + none / leaky / relu, 3: GDN, 4: inverse GDN
+        constexpr bool WH = decltype(WHOLE)::value;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          float v = acc[j][r];
-          if (gdn) {
-            const float nrm = __builtin_sqrtf(acc2[j][r] + cbeta[j]);
-            v = a.gdn == 2 ? v * nrm : v / nrm;
-          } else {
-            const float neg = act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v);
-            v = v > 0.0f ? v : neg;
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = acc[j][r];
+            if constexpr (MD >= 3) {
+              const float nrm = __builtin_sqrtf(acc2[j][r] + cbeta[j]);
+              v = MD == 4 ? v * nrm : v / nrm;
+            }
+            if constexpr (MD == 1) v = v > 0.0f ? v : v * 0.01f;
+            if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
+            if (WH || m < cols) yrow[(size_t)m * IC_CO + 32 * j] = v;
+            // keep the elements apart: interleaved sqrt / division sequences of many of them cost registers (the
+            // gamma fragments already take 64)
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (ox0 + m < a.wo) yrow[(size_t)m * IC_CO + 32 * j] = v;
         }
-      }
+      };
+      using std::integral_constant;
+      const int mode = gdn ? (a.gdn == 2 ? 4 : 3) : (a.act1 == AIVC_ACT_LEAKY ? 1 : (a.act1 == AIVC_ACT_RELU ? 2 : 0));
+      auto emit_m = [&](auto WHOLE) {
+        switch (mode) {
+          case 0: emit(integral_constant<int, 0>{}, WHOLE); break;
+          case 1: emit(integral_constant<int, 1>{}, WHOLE); break;
+          case 2: emit(integral_constant<int, 2>{}, WHOLE); break;
+          case 3: emit(integral_constant<int, 3>{}, WHOLE); break;
+          default: emit(integral_constant<int, 4>{}, WHOLE); break;
+        }
+      };
+      if (cols >= IC_TW) emit_m(integral_constant<bool, true>{});
+      else emit_m(integral_constant<bool, false>{});
     }
   }
 }
