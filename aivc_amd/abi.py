@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -20,6 +20,7 @@ ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 AC_MAX_VAL = 256
 LP = 514
 CDF_ROW = 520
+CDF_WIN0, CDF_WIN = 224, 64  # the decoder's fast-path window of a CDF row
 BALLE_PARAMS = 43
 MAX_MAPS = 256
 RC_MAX_STREAMS = 64
@@ -99,10 +100,12 @@ PROTOTYPES = {
     'aivc_balle_cdf_table': [_f, _i32, _f, _f],
     'aivc_nonzero_maps': [_f, _sz, _i32, _f],
     'aivc_laplace_cdf_rows': [_f, _sz, _i32, _P(MapList), _f],
+    'aivc_laplace_cdf_windows': [_f, _sz, _i32, _P(MapList), _f, _f],
     'aivc_laplace_bounds': [_f, _f, _sz, _i32, _P(MapList), _f],
     'aivc_table_bounds': [_f, _f, _sz, _i32, _f],
     'aivc_range_encode': [_f, _P(RcBatch), _f, _f],
     'aivc_range_decode': [_f, _f, _P(RcBatch), _f],
+    'aivc_range_decode_windows': [_f, _f, _f, _P(RcBatch), _f],
     'aivc_scatter_symbols': [_f, _sz, _i32, _P(MapList), _f],
 }
 

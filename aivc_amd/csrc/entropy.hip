@@ -101,6 +101,32 @@ __global__ __launch_bounds__(256) void laplace_cdf_rows_kernel(const float *__re
   *reinterpret_cast<uint4 *>(rows + pos * AIVC_CDF_ROW + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// The decoder's fast path only ever looks at the 64 entries DEC_WIN0 .. DEC_WIN0 + 63 of a row (symbols -32 .. +31);
+// this kernel produces just those (128 B per coded position instead of 1040) plus sigma of the position, from which
+// the decoder's slow path rebuilds the rest of a row on demand with the same function.
+constexpr int CDF_WIN0 = 224, CDF_WIN = 64;
+__global__ __launch_bounds__(256) void laplace_cdf_windows_kernel(const float *__restrict__ sigma, size_t npix, int c,
+                                                                  aivc_map_list maps, uint16_t *__restrict__ win,
+                                                                  float *__restrict__ sigma_pos) {
+  constexpr int CHUNKS = CDF_WIN / 8;  // 8 x 16 B per position
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)maps.n_maps * npix * CHUNKS;
+  if (gid >= total) return;
+  const int chunk = (int)(gid % CHUNKS);
+  const size_t pos = gid / CHUNKS;
+  const int m = (int)(pos / npix);
+  const size_t pix = pos % npix;
+  const float s = sigma[pix * c + maps.idx[m]];
+  if (chunk == 0) sigma_pos[pos] = s;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k0 = CDF_WIN0 + chunk * 8 + 2 * j;
+    w[j] = (uint32_t)aivc_laplace_cdf_u16(k0, s) | ((uint32_t)aivc_laplace_cdf_u16(k0 + 1, s) << 16);
+  }
+  *reinterpret_cast<uint4 *>(win + pos * CDF_WIN + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ __launch_bounds__(256) void laplace_bounds_kernel(const float *__restrict__ sigma,
                                                              const int16_t *__restrict__ q, size_t npix, int c,
                                                              aivc_map_list maps, uint32_t *__restrict__ bounds) {
@@ -311,6 +337,7 @@ struct BitWin {
 
 constexpr int DEC_D = 16;      // window prefetch depth (symbols): LDS ring of DEC_D slots
 constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
+static_assert(DEC_WIN0 == CDF_WIN0, "window position");
 
 // LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS, zero-extended): no
 // register, invisible to the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at
@@ -329,10 +356,15 @@ __device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, 
 // DEC_D - 1 symbols ahead with its offset bump (add + min: parked on the last row, no counter), two readlanes, the
 // interval update, and renormalisation only when a leading bit is final (skipped otherwise: at < 1 bit per
 // symbol most symbols shift nothing).
-template <bool PLANE>
+// WINDOWED: `rows` holds only the 64-entry window of every position (laplace_cdf_windows_kernel) and `sigma_pos` its
+// sigma: the slow path evaluates the entries it needs itself.
+template <bool PLANE, bool WINDOWED = false>
 __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes, const uint16_t *__restrict__ rows,
                                               const aivc_rc_stream &st, uint16_t *__restrict__ sym, uint32_t *ring,
-                                              const int lane) {
+                                              const int lane, const float *__restrict__ sigma_pos = nullptr) {
+  static_assert(!(PLANE && WINDOWED), "windows are per-position Laplace rows");
+  constexpr int ROWLEN = WINDOWED ? CDF_WIN : AIVC_CDF_ROW;  // uint16 entries per stored row
+  constexpr int WOFF = WINDOWED ? 0 : DEC_WIN0;              // position of the window inside a stored row
   BitWin bw;
   bw.in = reinterpret_cast<const uint32_t *>(bytes + st.in_off);
   bw.n_words = (st.in_len + 3u) / 4u;
@@ -343,17 +375,17 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
   const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
   const uint32_t n_sym = st.n_sym, plane = st.plane;
   const uint32_t n_rows = PLANE ? (n_sym + plane - 1u) / plane : n_sym;
-  const uint16_t *base = rows + st.row_off * AIVC_CDF_ROW;
-  auto row_of = [&](uint32_t i) -> const uint16_t * { return base + (uint64_t)(PLANE ? i / plane : i) * AIVC_CDF_ROW; };
+  const uint16_t *base = rows + st.row_off * ROWLEN;
+  auto row_of = [&](uint32_t i) -> const uint16_t * { return base + (uint64_t)(PLANE ? i / plane : i) * ROWLEN; };
   // prefetcher: per-lane byte offset of its window entry in the row of the symbol being fetched (host side: a
   // stream's rows span < 4 GiB)
-  uint32_t voff = (uint32_t)(DEC_WIN0 + lane) * 2u;
-  const uint32_t vlast = voff + (n_rows - 1u) * (uint32_t)(AIVC_CDF_ROW * 2);
+  uint32_t voff = (uint32_t)(WOFF + lane) * 2u;
+  const uint32_t vlast = voff + (n_rows - 1u) * (uint32_t)(ROWLEN * 2);
   uint32_t pf_slot = 0, pf_in_plane = 0;
   auto prefetch = [&]() {
     window_dma(base, voff, ring_base + pf_slot);
     pf_slot = (pf_slot + 256u) & (DEC_D * 256u - 1u);
-    uint32_t step = (uint32_t)(AIVC_CDF_ROW * 2);
+    uint32_t step = (uint32_t)(ROWLEN * 2);
     if (PLANE) {
       ++pf_in_plane;
       const bool wrap = pf_in_plane == plane;
@@ -395,15 +427,21 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
         // symbol outside [-32, 30]: fetch and search the whole row (8 entries per lane); rare
         uint32_t i = first + j;
         asm volatile("" : "+s"(i));  // rare path: no running row offset kept in the loop for it
-        const uint16_t *row = row_of(i);
-        const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
-        const uint32_t nx = row[lane * 8 + 8];
         uint32_t t[9];
-        t[0] = scaled(e.x & 0xFFFFu, hl); t[1] = scaled(e.x >> 16, hl);
-        t[2] = scaled(e.y & 0xFFFFu, hl); t[3] = scaled(e.y >> 16, hl);
-        t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
-        t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
-        t[8] = scaled(nx, hl);
+        if constexpr (WINDOWED) {
+          const float sg = sigma_pos[st.row_off + i];  // the row of this position, rebuilt: 9 entries per lane
+#pragma unroll
+          for (int k = 0; k < 9; ++k) t[k] = scaled((uint32_t)aivc_laplace_cdf_u16(lane * 8 + k, sg), hl);
+        } else {
+          const uint16_t *row = row_of(i);
+          const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
+          const uint32_t nx = row[lane * 8 + 8];
+          t[0] = scaled(e.x & 0xFFFFu, hl); t[1] = scaled(e.x >> 16, hl);
+          t[2] = scaled(e.y & 0xFFFFu, hl); t[3] = scaled(e.y >> 16, hl);
+          t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
+          t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
+          t[8] = scaled(nx, hl);
+        }
         uint32_t total = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
@@ -462,6 +500,19 @@ __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restr
   if (st.plane) decode_stream<true>(bytes, rows, st, sym, ring, lane);
   else decode_stream<false>(bytes, rows, st, sym, ring, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+}
+
+__global__ __launch_bounds__(64) void range_decode_windows_kernel(const uint8_t *__restrict__ bytes,
+                                                                  const uint16_t *__restrict__ win,
+                                                                  const float *__restrict__ sigma_pos, aivc_rc_batch batch,
+                                                                  uint16_t *__restrict__ sym) {
+  __shared__ uint32_t ring[DEC_D * 64];
+  const aivc_rc_stream st = batch.s[blockIdx.x];
+  const int lane = threadIdx.x;
+  if (st.n_sym == 0) return;
+  __builtin_amdgcn_s_setprio(3);
+  decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_pos);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace aivc
@@ -555,6 +606,31 @@ AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *b
   hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch,
                      out, out_len);
   return check_launch("range_encode");
+}
+
+AIVC_EXPORT int aivc_laplace_cdf_windows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps,
+                                         uint16_t *win, float *sigma_pos, aivc_stream_t stream) {
+  if (!sigma || !win || !sigma_pos || c <= 0) return AIVC_ERR_ARG;
+  if (int rc = check_maps(maps, c)) return rc;
+  const size_t total = (size_t)maps->n_maps * npix * (CDF_WIN / 8);
+  if (total == 0) return AIVC_OK;
+  hipLaunchKernelGGL(laplace_cdf_windows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), sigma, npix, c,
+                     *maps, win, sigma_pos);
+  return check_launch("laplace_cdf_windows");
+}
+
+AIVC_EXPORT int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *win, const float *sigma_pos,
+                                          const aivc_rc_batch *batch, uint16_t *sym, aivc_stream_t stream) {
+  if (!bytes || !win || !sigma_pos || !sym) return AIVC_ERR_ARG;
+  if (int rc = check_batch(batch)) return rc;
+  if (batch->n_streams == 0) return AIVC_OK;
+  for (int i = 0; i < batch->n_streams; ++i) {
+    if (batch->s[i].in_off % 4 || batch->s[i].plane != 0) return AIVC_ERR_ARG;
+    if (((uint64_t)batch->s[i].n_sym + 1) * (uint64_t)(CDF_WIN * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(range_decode_windows_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, win,
+                     sigma_pos, *batch, sym);
+  return check_launch("range_decode_windows");
 }
 
 AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_batch *batch,

@@ -501,6 +501,24 @@ def laplace_cdf_rows(sigma, maps, out=None, row_off=0):
     return out
 
 
+def laplace_cdf_windows(sigma, maps, out=None, row_off=0):
+    """Like laplace_cdf_rows, restricted to the decoder's fast-path window: -> (win [n_pos, CDF_WIN] int16,
+    sigma_pos [n_pos] float32); with `out` = (win, sigma_pos) given, written from position `row_off` on."""
+    sigma = _dev(sigma, torch.float32, 'sigma')
+    c = sigma.shape[-1]
+    npix = sigma.numel() // c
+    ml = abi.MapList.make(maps)
+    if out is None:
+        out = (torch.empty((len(maps) * npix, abi.CDF_WIN), dtype=torch.int16, device=sigma.device),
+               torch.empty(len(maps) * npix, dtype=torch.float32, device=sigma.device))
+        row_off = 0
+    win, sp = out
+    _hbm_profiled('laplace_cdf_rows', len(maps) * npix * (8 + 2 * abi.CDF_WIN),
+                  lambda: call('aivc_laplace_cdf_windows', _p(sigma), npix, c, C.byref(ml),
+                               win.data_ptr() + 2 * row_off * abi.CDF_WIN, sp.data_ptr() + 4 * row_off, _stream()))
+    return out
+
+
 def laplace_bounds(sigma, q, maps):
     sigma, q = _dev(sigma, torch.float32, 'sigma'), _dev(q, torch.int16, 'q')
     c = sigma.shape[-1]
@@ -586,10 +604,12 @@ def range_encode(bounds_list, streams=None):
     return out, lens, out_offs
 
 
-def range_decode(payloads, rows, row_offs, n_syms, planes):
+def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None):
     """Decode len(payloads) independent streams concurrently (one wavefront each, <= 64 per launch).
     rows: ONE int16 CUDA tensor [n_rows, CDF_ROW] holding every stream's CDF rows; stream i starts at
     row row_offs[i] and uses one row per symbol (planes[i] == 0) or row i // planes[i] (pmf tables).
+    With sigma_pos (float32 [n_rows]) `rows` holds the 64-entry windows of laplace_cdf_windows instead
+    ([n_rows, CDF_WIN]; planes must be 0).
     Returns a list of int16 CUDA tensors (uint16 payload: symbols 0..512)."""
     n = len(payloads)
     dev = rows.device
@@ -620,7 +640,10 @@ def range_decode(payloads, rows, row_offs, n_syms, planes):
             so += n_syms[i]
             cnt += 1
         batch.n_streams = cnt
-        call('aivc_range_decode', _p(dbytes), _p(rows), C.byref(batch), _p(sym), _stream())
+        if sigma_pos is None:
+            call('aivc_range_decode', _p(dbytes), _p(rows), C.byref(batch), _p(sym), _stream())
+        else:
+            call('aivc_range_decode_windows', _p(dbytes), _p(rows), _p(sigma_pos), C.byref(batch), _p(sym), _stream())
     return outs
 
 

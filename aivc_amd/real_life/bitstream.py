@@ -6,9 +6,10 @@ Frame bitstream = 4 sections in fixed order mofnet_z, mofnet_y, codecnet_z, code
 frame carries two empty (4 zero bytes) MOFNet sections; an all-zero y is the single byte 0.
 
 What differs from the reference implementation (not from its bytes): the [C,H,W,514] fp32 CDF is
-never materialised -- the encoder evaluates the 2 CDF points a symbol needs, the decoder reads a
-uint16 row per position that another kernel produced, z uses a [C_z,514] table built once; there is
-no device->host copy of CDFs and no temp file.
+never materialised -- the encoder evaluates the 2 CDF points a symbol needs, the decoder reads the
+64-entry uint16 window around zero of a position's row (another kernel produced it, with sigma beside it for
+the rare symbol outside), z uses a [C_z,514] table built once; there is no device->host copy of CDFs and no
+temp file.
 """
 import os
 
@@ -62,17 +63,20 @@ _ROWS_WS = {}
 
 
 def _rows_workspace(n_rows, device):
-    """Caller-owned scratch for the decoder's CDF rows (1040 B per coded symbol): grown
-    monotonically and reused -- multi-GB allocations of varying size otherwise go back to hipMalloc
-    on every batch.  One buffer per (device, stream): the entropy stage runs on its own stream."""
+    """Caller-owned scratch for the decoder's CDF windows (64 entries = 128 B per coded symbol, + its sigma):
+    grown monotonically and reused -- large allocations of varying size otherwise go back to hipMalloc
+    on every batch.  One buffer per (device, stream): the entropy stage runs on its own stream.
+    -> (win [n_rows, CDF_WIN] int16, sigma_pos [n_rows] float32)"""
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     ws = _ROWS_WS.get(key)
-    if ws is None or ws.shape[0] < n_rows:
+    if ws is None or ws[0].shape[0] < n_rows:
         ws = None
         _ROWS_WS.pop(key, None)
-        ws = torch.empty((int(n_rows * 1.25) + 1024, abi.CDF_ROW), dtype=torch.int16, device=device)
+        cap = int(n_rows * 1.25) + 1024
+        ws = (torch.empty((cap, abi.CDF_WIN), dtype=torch.int16, device=device),
+              torch.empty(cap, dtype=torch.float32, device=device))
         _ROWS_WS[key] = ws
-    return ws[:n_rows]
+    return ws[0][:n_rows], ws[1][:n_rows]
 
 
 _PIN_POOL = {}
@@ -291,11 +295,14 @@ class ArithmeticCoder():
         live = [i for i in range(n) if maps[i]]
         syms = {}
         if live:
-            rows = _rows_workspace(total, sigma.device)
+            # 64-entry CDF windows (what the decoder's fast path reads) + sigma per position; symbols outside the
+            # window make the decoder rebuild the row itself -- 128 B and 64 CDF points per symbol instead of 1040 / 514
+            win, sig = _rows_workspace(total, sigma.device)
             for i in live:
-                ops.laplace_cdf_rows(sigma[i:i + 1], maps[i], out=rows, row_off=row_offs[i])
-            dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], rows,
-                                   [row_offs[i] for i in live], [len(maps[i]) * npix for i in live], [0] * len(live))
+                ops.laplace_cdf_windows(sigma[i:i + 1], maps[i], out=(win, sig), row_off=row_offs[i])
+            dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], win,
+                                   [row_offs[i] for i in live], [len(maps[i]) * npix for i in live], [0] * len(live),
+                                   sigma_pos=sig)
             syms = dict(zip(live, dec))
         q = torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
         self._check_md5(q, sums, 'y latent')

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 6 */
+int aivc_abi_version(void); /* currently 7 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -294,6 +294,15 @@ typedef struct aivc_map_list {
  * the fp32 [C,H,W,514] tensor. */
 int aivc_laplace_cdf_rows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps,
                           uint16_t *rows, aivc_stream_t stream);
+
+/* The same rows restricted to what the range decoder's fast path reads: the AIVC_CDF_WIN entries from AIVC_CDF_WIN0 on
+ * (symbols -32 .. +31) of every coded position, 128 B instead of 1040, and sigma of the position (from which
+ * aivc_range_decode_windows rebuilds the rest of a row with the same function when a symbol falls outside):
+ *   win[p][j] = rows[p][AIVC_CDF_WIN0 + j],  sigma_pos[p] = sigma[pix][maps.idx[m]]. */
+#define AIVC_CDF_WIN0 224
+#define AIVC_CDF_WIN 64
+int aivc_laplace_cdf_windows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps, uint16_t *win,
+                             float *sigma_pos, aivc_stream_t stream);
 /* Encoder: only the two CDF values a symbol needs.  bounds[p] = c_lo | (c_hi << 16) with
  * c_lo = cdf_u16[sym], c_hi = cdf_u16[sym+1], sym = q + 256. */
 int aivc_laplace_bounds(const float *sigma, const int16_t *q, size_t npix, int32_t c,
@@ -326,6 +335,10 @@ int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *batch, uint8_
 /* decode: sym[out_off + i] = decoded symbol in [0, 512]. */
 int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_batch *batch,
                       uint16_t *sym, aivc_stream_t stream);
+/* Laplace-mode decode from windows (aivc_laplace_cdf_windows): stream i starts at position row_off of win / sigma_pos,
+ * one position per symbol (plane must be 0).  Same symbols as aivc_range_decode on the full rows. */
+int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *win, const float *sigma_pos,
+                              const aivc_rc_batch *batch, uint16_t *sym, aivc_stream_t stream);
 /* Scatter decoded symbols back to the latent: q[pix][maps.idx[m]] = sym[m*npix + pix] - 256,
  * all other channels 0.  (src/real_life/bitstream.py:458-466) */
 int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c, const aivc_map_list *maps,

@@ -366,6 +366,35 @@ def laplace_cdf_rows(sigma, maps):
     return rows
 
 
+def laplace_cdf_windows(sigma, maps):
+    """-> (win [n_pos][CDF_WIN] uint16, sigma_pos [n_pos] float32): the decoder's fast-path window of every row"""
+    sigma = _f32(sigma)
+    c = sigma.shape[-1]
+    npix = sigma.size // c
+    ml = abi.MapList.make(maps)
+    win = np.empty((len(maps) * npix, abi.CDF_WIN), np.uint16)
+    sp = np.empty(len(maps) * npix, np.float32)
+    _chk(lib()['aivc_laplace_cdf_windows'](_p(sigma), npix, c, C.byref(ml), _p(win), _p(sp), None),
+         'aivc_laplace_cdf_windows')
+    return win, sp
+
+
+def range_decode_windows(payload, win, sigma_pos, n_sym):
+    win = np.ascontiguousarray(win, np.uint16)
+    sigma_pos = _f32(sigma_pos)
+    buf = np.frombuffer(payload, np.uint8)
+    padded = np.zeros((len(buf) + 3) // 4 * 4 + 8, np.uint8)
+    padded[:len(buf)] = buf
+    sym = np.empty(n_sym, np.uint16)
+    b = abi.RcBatch()
+    b.n_streams = 1
+    s = b.s[0]
+    s.in_off, s.out_off, s.row_off, s.n_sym, s.in_len, s.plane = 0, 0, 0, n_sym, len(buf), 0
+    _chk(lib()['aivc_range_decode_windows'](_p(padded), _p(win), _p(sigma_pos), C.byref(b), _p(sym), None),
+         'aivc_range_decode_windows')
+    return sym
+
+
 def laplace_bounds(sigma, q, maps):
     sigma = _f32(sigma)
     q = np.ascontiguousarray(q, np.int16)

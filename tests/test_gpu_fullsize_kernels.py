@@ -82,8 +82,8 @@ def test_range_coder_round_trip_4k_latent(cuda):
     nbytes = int(lens.cpu()[0])
     payload = out[offs[0][0]:offs[0][0] + nbytes].cpu().numpy().tobytes()
     assert 0 < nbytes < 2 * h * w * c
-    rows = ops.laplace_cdf_rows(sigma, maps)
-    dec = ops.range_decode([payload], rows, [0], [h * w * c], [0])[0]
+    win, sp = ops.laplace_cdf_windows(sigma, maps)
+    dec = ops.range_decode([payload], win, [0], [h * w * c], [0], sigma_pos=sp)[0]
     want = (q.permute(3, 0, 1, 2).reshape(-1).to(torch.int32) + 256).to(torch.int16)
     assert (q.abs() > 40).any(), 'the sweep must leave the 64-entry window'
     assert torch.equal(dec.view(torch.int16).reshape(-1), want)

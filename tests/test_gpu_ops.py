@@ -211,6 +211,33 @@ def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
     eq(got_sym, ref_sym)
 
 
+@pytest.mark.parametrize('scale', [0.4, 3.0, 40.0])
+def test_range_decode_from_windows(scale, oracle, cuda):
+    """64-entry CDF windows + sigma per position (what the codec's decoder reads) give the symbols of the full rows,
+    in and outside the window; the windows equal the oracle's and the slice of the full rows"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(int(scale * 10))
+    h, w, c = 9, 13, 6
+    maps = [0, 2, 5]
+    sig = (np.abs(rng.standard_normal((1, h, w, c))) * scale + 0.05).astype(np.float32)
+    q = np.clip(np.rint(rng.standard_normal((1, h, w, c)) * sig), -256, 255).astype(np.int16)
+    bounds = oracle.laplace_bounds(sig, q, maps)
+    payload = oracle.range_encode(bounds)
+    rows = oracle.laplace_cdf_rows(sig, maps)
+    n_sym = len(maps) * h * w
+    want = oracle.range_decode(payload, rows, n_sym)
+    win_o, sp_o = oracle.laplace_cdf_windows(sig, maps)
+    np.testing.assert_array_equal(win_o, rows[:, abi.CDF_WIN0:abi.CDF_WIN0 + abi.CDF_WIN])
+    np.testing.assert_array_equal(oracle.range_decode_windows(payload, win_o, sp_o, n_sym), want)
+    win, sp = ops.laplace_cdf_windows(T(sig, cuda), maps)
+    eq(win, win_o)
+    eq(sp, sp_o)
+    got = ops.range_decode([payload], win, [0], [n_sym], [0], sigma_pos=sp)[0]
+    eq(got, want)
+    if scale >= 40.0:
+        assert (np.abs(q[..., maps]) > 32).any(), 'the slow path (symbol outside the window) must be exercised'
+
+
 def test_range_coder_pmf_and_scatter(oracle, cuda):
     from aivc_amd import ops
     rng = np.random.default_rng(11)

@@ -83,3 +83,19 @@ def test_empty_and_single(oracle):
     b = oracle.laplace_bounds(np.ones((1, 1, 1, 1), np.float32), np.zeros((1, 1, 1, 1), np.int16), [0])
     payload = oracle.range_encode(b)
     assert oracle.range_decode(payload, oracle.laplace_cdf_rows(np.ones((1, 1, 1, 1), np.float32), [0]), 1)[0] == 256
+
+
+def test_windows_twin_matches_full_rows(oracle):
+    """oracle: the 64-entry windows are a slice of the rows, and decoding from them returns the same symbols"""
+    import numpy as np
+    from aivc_amd import abi
+    rng = np.random.default_rng(3)
+    sig = (np.abs(rng.standard_normal((1, 5, 7, 4))) * 20.0 + 0.05).astype(np.float32)
+    q = np.clip(np.rint(rng.standard_normal((1, 5, 7, 4)) * sig), -256, 255).astype(np.int16)
+    maps = [1, 3]
+    payload = oracle.range_encode(oracle.laplace_bounds(sig, q, maps))
+    rows = oracle.laplace_cdf_rows(sig, maps)
+    win, sp = oracle.laplace_cdf_windows(sig, maps)
+    np.testing.assert_array_equal(win, rows[:, abi.CDF_WIN0:abi.CDF_WIN0 + abi.CDF_WIN])
+    n = 2 * 35
+    np.testing.assert_array_equal(oracle.range_decode_windows(payload, win, sp, n), oracle.range_decode(payload, rows, n))
