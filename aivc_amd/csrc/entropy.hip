@@ -427,12 +427,22 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
         // symbol outside [-32, 30]: fetch and search the whole row (8 entries per lane); rare
         uint32_t i = first + j;
         asm volatile("" : "+s"(i));  // rare path: no running row offset kept in the loop for it
-        uint32_t t[9];
         if constexpr (WINDOWED) {
-          const float sg = sigma_pos[st.row_off + i];  // the row of this position, rebuilt: 9 entries per lane
-#pragma unroll
-          for (int k = 0; k < 9; ++k) t[k] = scaled((uint32_t)aivc_laplace_cdf_u16(lane * 8 + k, sg), hl);
+          // the row of this position is rebuilt from its sigma, two CDF points per lane: a coarse pass over every
+          // 8th entry finds the octet, a fine pass over its 9 entries the symbol (entries increase strictly)
+          const float sg = sigma_pos[st.row_off + i];
+          const uint32_t tc = scaled((uint32_t)aivc_laplace_cdf_u16(lane * 8, sg), hl);
+          const uint32_t cc = (uint32_t)__builtin_popcountll(__ballot(tc <= d));
+          const uint32_t L = cc > 0 ? cc - 1u : 0u;
+          const uint32_t tf = scaled((uint32_t)aivc_laplace_cdf_u16((int)(8u * L) + min(lane, 8), sg), hl);
+          const uint32_t cf = (uint32_t)__builtin_popcountll(__ballot(lane < 8 && tf <= d));
+          const uint32_t total = cc > 0 ? 8u * L + cf : 0u;  // entries 0 .. 511 that are <= d
+          m = total > 0 ? total - 1u : 0u;
+          const int idx = (int)(m - 8u * L);
+          t_lo = rl(tf, idx);
+          t_hi = rl(tf, idx + 1);
         } else {
+          uint32_t t[9];
           const uint16_t *row = row_of(i);
           const uint4 e = *reinterpret_cast<const uint4 *>(row + lane * 8);
           const uint32_t nx = row[lane * 8 + 8];
@@ -441,21 +451,21 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
           t[4] = scaled(e.z & 0xFFFFu, hl); t[5] = scaled(e.z >> 16, hl);
           t[6] = scaled(e.w & 0xFFFFu, hl); t[7] = scaled(e.w >> 16, hl);
           t[8] = scaled(nx, hl);
-        }
-        uint32_t total = 0;
+          uint32_t total = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
-        m = total > 0 ? total - 1 : 0;
-        const int L = (int)(m >> 3);
-        const uint32_t idx = m & 7u;
-        uint32_t s_lo = t[0], s_hi = t[1];
+          for (int k = 0; k < 8; ++k) total += (uint32_t)__builtin_popcountll(__ballot(t[k] <= d));
+          m = total > 0 ? total - 1 : 0;
+          const int L = (int)(m >> 3);
+          const uint32_t idx = m & 7u;
+          uint32_t s_lo = t[0], s_hi = t[1];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-          s_lo = idx == (uint32_t)k ? t[k] : s_lo;
-          s_hi = idx == (uint32_t)k ? t[k + 1] : s_hi;
+          for (int k = 1; k < 8; ++k) {
+            s_lo = idx == (uint32_t)k ? t[k] : s_lo;
+            s_hi = idx == (uint32_t)k ? t[k + 1] : s_hi;
+          }
+          t_lo = rl(s_lo, L);
+          t_hi = rl(s_hi, L);
         }
-        t_lo = rl(s_lo, L);
-        t_hi = rl(s_hi, L);
         if (m == 511u && t_hi <= d) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign
           m = 512u;                    // streams -- its upper bound is 2^16, i.e. t = span: high stays
           t_lo = t_hi;
