@@ -163,7 +163,16 @@ def cpu_baseline(width, height, model, fc, dev):
     return out
 
 
+_REAL_STDOUT = 1
+
+
 def main():
+    # stdout carries exactly one line (the result); file descriptor 1 is pointed at stderr for everything else,
+    # including native libraries that print there
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
@@ -428,10 +437,15 @@ def main():
             out['invalid'] = 'tiny debug model'
         if use_dist and backend != 'nccl':
             out['invalid'] = 'validation run over %s, not RCCL' % backend
-        print(json.dumps(out))
+        line = json.dumps(out)
     if use_dist:
         dist.barrier()  # the other ranks wait for rank 0's instrumented step before tearing RCCL down
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes to the real stdout; everything libraries print there (RCCL's version banner, its
+        # warnings) was sent to stderr by main()'s redirection
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (line + '\n').encode())
 
 
 if __name__ == '__main__':
