@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2

@@ -135,10 +135,11 @@ __global__ __launch_bounds__(256) void laplace_bounds_kernel(const float *__rest
   const int ch = maps.idx[pos / npix];
   const size_t pix = pos % npix;
   const float s = sigma[pix * c + ch];
-  // symbols outside the alphabet [0, 511] never reach this kernel through the codec (quantize_center clamps,
-  // the path API raises like torchac's check_input_bounds); the clamp keeps a misuse memory-safe
-  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), 2 * AIVC_AC_MAX_VAL - 1);
-  const uint32_t lo = aivc_laplace_cdf_u16(sym, s), hi = aivc_laplace_cdf_u16(sym + 1, s);
+  // symbols outside the alphabet [0, 512] never reach this kernel through the codec (quantize_center clamps,
+  // the path API raises like torchac's check_input_bounds); the clamp keeps a misuse memory-safe.
+  // Symbol 512 (torchac's max_symbol): upper bound 2^16, packed as 0 (include/aivc_hip.h)
+  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), AIVC_MAX_SYMBOL);
+  const uint32_t lo = aivc_laplace_cdf_u16(sym, s), hi = sym == AIVC_MAX_SYMBOL ? 0u : aivc_laplace_cdf_u16(sym + 1, s);
   bounds[pos] = lo | (hi << 16);
 }
 
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(256) void table_bounds_kernel(const uint16_t *__res
   if (pos >= (size_t)c * npix) return;
   const int ch = (int)(pos / npix);
   const size_t pix = pos % npix;
-  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), 2 * AIVC_AC_MAX_VAL - 1);
+  const int sym = min(max((int)q[pix * c + ch] + AIVC_AC_MAX_VAL, 0), AIVC_MAX_SYMBOL);
   const uint16_t *row = table + (size_t)ch * AIVC_CDF_ROW;
-  bounds[pos] = (uint32_t)row[sym] | ((uint32_t)row[sym + 1] << 16);
+  bounds[pos] = (uint32_t)row[sym] | (sym == AIVC_MAX_SYMBOL ? 0u : (uint32_t)row[sym + 1] << 16);
 }
 
 struct InvMap {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
   for (uint32_t base = 0; base < st.n_sym; base += 64) {
     const uint32_t mine = nxt;
     nxt = (base + 64u + lane < st.n_sym) ? src[base + 64u + lane] : 0u;
-    const uint32_t vlo = mine & 0xFFFFu, vhi = mine >> 16;
+    const uint32_t vlo = mine & 0xFFFFu, vhi = (mine >> 16) ? (mine >> 16) : 0x10000u;  // 0 = 2^16: symbol 512
     const uint32_t cnt = min(64u, st.n_sym - base);
 #pragma unroll 1
     for (uint32_t j = 0; j < cnt; ++j) {
@@ -466,8 +467,8 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
           t_lo = rl(s_lo, L);
           t_hi = rl(s_hi, L);
         }
-        if (m == 511u && t_hi <= d) {  // symbol 512 (never produced by our encoder): torchac semantics on foreign
-          m = 512u;                    // streams -- its upper bound is 2^16, i.e. t = span: high stays
+        if (m == 511u && t_hi <= d) {  // symbol 512 (value +256, torchac's max_symbol): its upper bound is 2^16,
+          m = 512u;                    // i.e. t = span: high stays
           t_lo = t_hi;
           t_hi = hl + 1u;
         }

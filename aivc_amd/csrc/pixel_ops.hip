@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void quantize_center_kernel(const float *__res
   if (gid >= total) return;
   const float m = mu ? mu[gid] : 0.0f;
   float r = __builtin_rintf(mu ? y[gid] - m : y[gid]);
-  r = r < -256.0f ? -256.0f : (r > 255.0f ? 255.0f : r);
+  r = r < -256.0f ? -256.0f : (r > 256.0f ? 256.0f : r);  // the alphabet of the coder: symbols 0 .. 512
   if (q) q[gid] = (int16_t)r;
   if (y_hat) {
     float v = mu ? r + m : r;

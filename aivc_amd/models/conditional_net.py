@@ -31,7 +31,7 @@ class ConditionalNet(Module):
     def __init__(self, param):
         super().__init__()
         default = {'in_c': 3, 'in_c_shortcut': 3, 'out_c': 3, 'widths': arch.DEFAULT_WIDTHS,
-                   'nb_rates': 1, 'flag_gain_p_b': True}
+                   'nb_rates': 1, 'flag_gain_p_b': True, 'flag_g_a_ref': True}
         in_c = get_value('in_c', param, default)
         in_c_shortcut = get_value('in_c_shortcut', param, default)
         out_c = get_value('out_c', param, default)
@@ -41,7 +41,9 @@ class ConditionalNet(Module):
         self.nb_ft_z = wd['c_z']
         self.out_c_shortcut_y = wd['c_short']
         self.g_a = arch.analysis_transform(in_c, self.nb_ft_y, wd)
-        self.g_a_ref = arch.analysis_transform(in_c_shortcut, self.out_c_shortcut_y, wd)
+        # "Some models don't have the shortcut transform" (src/real_life/decode.py:772-776): g_s then sees zeros
+        self.g_a_ref = arch.analysis_transform(in_c_shortcut, self.out_c_shortcut_y, wd) \
+            if get_value('flag_g_a_ref', param, default) else None
         self.g_s = arch.synthesis_transform(self.nb_ft_y + self.out_c_shortcut_y, out_c, wd)
         self.h_a = arch.hyper_analysis(self.nb_ft_y, self.nb_ft_z, wd)
         self.h_s = arch.hyper_synthesis(self.nb_ft_z, self.nb_ft_y, wd)

@@ -44,11 +44,11 @@ def _to_float_dic(planes):
 class FullNet(Module):
     def __init__(self, model_param=None):
         super().__init__()
-        default = {'widths': arch.DEFAULT_WIDTHS, 'nb_rates': 1, 'flag_gain_p_b': True,
+        default = {'widths': arch.DEFAULT_WIDTHS, 'nb_rates': 1, 'flag_gain_p_b': True, 'flag_g_a_ref': True,
                    'lambda_tradeoff': [0.01]}
         self.model_param = dict(default)
         self.model_param.update(model_param or {})
-        sub = {k: self.model_param[k] for k in ('widths', 'nb_rates', 'flag_gain_p_b')}
+        sub = {k: self.model_param[k] for k in ('widths', 'nb_rates', 'flag_gain_p_b', 'flag_g_a_ref')}
         self.in_layer = InputLayer()
         self.out_layer = OutputLayer()
         self.mode_net = ModeNet(sub)

@@ -319,13 +319,13 @@ class ArithmeticCoder():
         latent_name = get_value('latent_name', param, default)
         if not path.endswith(BITSTREAM_SUFFIX):
             path += BITSTREAM_SUFFIX
-        # torchac.encode_float_cdf(..., check_input_bounds=True) raises on symbols outside the alphabet
-        # (src/real_life/bitstream.py:280-281); value AC_MAX_VAL itself (symbol Lp - 2) is legal there but is
-        # never produced by the codec and not representable in the packed 16-bit bounds of these kernels
-        lo, hi = float(x.min()), float(x.max())
-        if lo < -self.AC_MAX_VAL or hi > self.AC_MAX_VAL - 1:
-            raise ValueError('ArithmeticCoder.encode: values in [%g, %g] outside [-%d, %d]'
-                             % (lo, hi, self.AC_MAX_VAL, self.AC_MAX_VAL - 1))
+        # torchac.encode_float_cdf(..., check_input_bounds=True) raises on symbols outside the alphabet 0 .. Lp - 2 = 512
+        # (src/real_life/bitstream.py:280-281), i.e. on values outside [-AC_MAX_VAL, AC_MAX_VAL]; one device sync
+        if x.numel():
+            lo, hi = (float(v) for v in torch.aminmax(x))
+            if lo < -self.AC_MAX_VAL or hi > self.AC_MAX_VAL:
+                raise ValueError('ArithmeticCoder.encode: values in [%g, %g] outside [-%d, %d]'
+                                 % (lo, hi, self.AC_MAX_VAL, self.AC_MAX_VAL))
         q = ops.to_nhwc(x).to(torch.int16)
         keep, self.flag_md5sum = self.flag_md5sum, bool(get_value('flag_md5sum', param, default))
         try:

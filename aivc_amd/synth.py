@@ -10,7 +10,7 @@ from .models import arch
 from .models.full_net import FullNet
 
 
-def synthetic_video(width, height, n_frames, seed=666, first=0):
+def synthetic_video(width, height, n_frames, seed=666, first=0, noise=4.0):
     """Planar 8-bit I420 frames: smooth translating pattern + noise.
     -> list of dicts {'y','u','v'} of uint8 numpy arrays."""
     rng = np.random.default_rng(seed)
@@ -24,7 +24,7 @@ def synthetic_video(width, height, n_frames, seed=666, first=0):
         v = 128 + 40 * np.cos(2 * np.pi * (yc - t) / 41) * np.sin(2 * np.pi * xc / 59)
         f = {}
         for k, a, shp in (('y', y, (height, width)), ('u', u, (hc, wc)), ('v', v, (hc, wc))):
-            a = a + rng.normal(0, 4, shp)
+            a = a + rng.normal(0, noise, shp)
             f[k] = np.clip(np.rint(a), 0, 255).astype(np.uint8)
         out.append(f)
     return out

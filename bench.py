@@ -166,6 +166,22 @@ def cpu_baseline(width, height, model, fc, dev):
 _REAL_STDOUT = 1
 
 
+def _self_launch(n):
+    """re-exec this script under torch.distributed.run with n ranks on this node"""
+    import socket
+    import subprocess
+    if not os.environ.get('AIVC_BENCH_SINGLE_DEVICE') and torch.cuda.device_count() < n:
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible' % (n, torch.cuda.device_count()))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    os.dup2(_REAL_STDOUT, 1)  # the child job's rank 0 writes the one line there
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     # stdout carries exactly one line (the result); file descriptor 1 is pointed at stderr for everything else,
     # including native libraries that print there
@@ -189,9 +205,18 @@ def main():
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--active-y', type=str, default='6,12',
+                    help='non-zero y feature maps MOFNet,CodecNet the synthetic model is calibrated to (64,64 = high rate)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL), exactly the
+        # command the driver uses; rank 0 of the child job prints the line on the stdout we hand down
+        return _self_launch(args.gpus)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but launched with WORLD_SIZE=%d' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -211,7 +236,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    strong = args.scaling == 'strong' or (args.scaling == 'auto')
+    strong = args.scaling == 'strong' or (args.scaling == 'auto')  # the label: same total work whatever N
+    sharded = strong and use_dist  # ClipShard path; at N = 1 strong and weak are the same single-process run
 
     from aivc_amd import ops, parallel, synth
     from aivc_amd.func_util.GOP_structure import generate_gop_struct
@@ -219,7 +245,7 @@ def main():
     widths = arch.TINY_WIDTHS if args.tiny else arch.DEFAULT_WIDTHS
     seed = 1234
     model = synth.make_model(widths, seed=seed, device=dev)
-    active_y = (6, 12)
+    active_y = tuple(int(v) for v in args.active_y.split(','))
     synth.calibrate_operating_point(model, dev, active_y=active_y)
     if use_dist:
         parallel.broadcast_model(model)  # the one collective on the weights: RCCL over xGMI
@@ -237,7 +263,7 @@ def main():
         return [fr[u * unit:(u + 1) * unit] for u in range(n_units)]
 
     n_total = args.warmup + args.steps + 1
-    shard = parallel.ClipShard(n_units, dev) if strong else None
+    shard = parallel.ClipShard(n_units, dev) if sharded else None
     # strong: every rank holds the same clips; weak: rank r codes clips r, r + world, ...
     clips = [make_clip(i if strong else rank + i * world) for i in range(n_total)]
     torch.cuda.synchronize()
@@ -409,20 +435,22 @@ def main():
         r_ = shard.R if shard is not None else 1
         out = {
             'metric': 'encode+decode fps @1080p YUV420 (RA GOP32)',
-            'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s',
+            'n_gpus': dist.get_world_size() if use_dist else 1, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%dx%d 8-bit YUV420, coding structure %s: one %d-frame clip = %d intra-period units of %d frames '
                                    '(%d coded frames, the last %d repeat the last frame) encoded + decoded per step; synthetic '
                                    'random-init stand-in for model ms_ssim-4 (widths %s), last analysis conv calibrated so that '
-                                   '%d (MOFNet) / %d (CodecNet) of the %d y feature maps are non-zero (low-rate operating point); %s'
+                                   '%d (MOFNet) / %d (CodecNet) of the %d y feature maps are non-zero (%s operating point); %s'
                                    % (args.width, args.height, args.gop, args.frames, n_units, unit, coded, coded - args.frames, widths,
                                       active_y[0], active_y[1], widths['c_y'],
+                                      'high-rate' if active_y[1] >= widths['c_y'] else 'low-rate',
                                       ('the clip sharded over %d GPUs: %d unit groups x %d ranks of temporal-layer sharding' % (world, g, r_))
-                                      if strong else 'one clip per GPU (replicas)'),
+                                      if sharded else ('one GPU' if world == 1 else 'one clip per GPU (replicas)')),
                        'requested_frames_per_step': args.frames, 'coded_frames_per_step': coded, 'units_per_step': n_units,
                        'nonzero_y_maps': {'mofnet': active_y[0], 'codecnet': active_y[1], 'of': widths['c_y']},
-                       'parallelism': ('unit-groups x%d, level-sharded x%d' % (g, r_)) if strong else 'replicas x%d' % world},
+                       'parallelism': ('unit-groups x%d, level-sharded x%d' % (g, r_)) if sharded else ('single GPU' if world == 1 else 'replicas x%d' % world)},
             'coded_frames_per_s': round(clips_done * coded / elapsed, 4),
             'encode_fps_rank0': round(args.steps * args.frames / stats['enc_s'], 3),
             'decode_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),

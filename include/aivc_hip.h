@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 7 */
+int aivc_abi_version(void); /* currently 8 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -263,6 +263,7 @@ int aivc_dequantize(const int16_t *q, const float *mu, const float *gain_dec, si
  * ---------------------------------------------------------------------------------------- */
 #define AIVC_AC_MAX_VAL 256
 #define AIVC_LP 514      /* CDF points per symbol: 2*AC_MAX_VAL + 2             */
+#define AIVC_MAX_SYMBOL 512 /* torchac's max_symbol = Lp - 2 (value +256): legal, upper bound 2^16 */
 #define AIVC_CDF_ROW 520 /* uint16 per stored CDF row (514 used, 1040 B = 65 x 16 B) */
 #define AIVC_BALLE_PARAMS 43 /* floats per channel, see aivc_balle_cdf_table */
 #define AIVC_MAX_MAPS 256
@@ -304,7 +305,10 @@ int aivc_laplace_cdf_rows(const float *sigma, size_t npix, int32_t c, const aivc
 int aivc_laplace_cdf_windows(const float *sigma, size_t npix, int32_t c, const aivc_map_list *maps, uint16_t *win,
                              float *sigma_pos, aivc_stream_t stream);
 /* Encoder: only the two CDF values a symbol needs.  bounds[p] = c_lo | (c_hi << 16) with
- * c_lo = cdf_u16[sym], c_hi = cdf_u16[sym+1], sym = q + 256. */
+ * c_lo = cdf_u16[sym], c_hi = cdf_u16[sym+1], sym = q + 256 in [0, 512].  For sym = 512 (torchac's max_symbol)
+ * the upper bound is 2^16 whatever the row holds (torchac: `sym == max_symbol ? 0x10000 : cdf[sym + 1]`); it is
+ * packed as c_hi = 0, which no other symbol can have (c_hi > c_lo >= 0), and aivc_range_encode reads 0 as 2^16
+ * (ABI 8). */
 int aivc_laplace_bounds(const float *sigma, const int16_t *q, size_t npix, int32_t c,
                         const aivc_map_list *maps, uint32_t *bounds, aivc_stream_t stream);
 /* Same from a per-channel table (pmf mode, all c channels, channel-major). */

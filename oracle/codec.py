@@ -118,8 +118,12 @@ def cond_encode(net, x_in, in_shortcut, frame_type, idx_rate=0.):
     return x_out, _z_section(table, q_z), _y_section(sigma, q_y), (h_y, w_y), tuple(z.shape[1:3])
 
 
-def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z, idx_rate=0.):
-    """src/real_life/decode.py:798-898"""
+def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z, idx_rate=0., sigma_hook=None):
+    """src/real_life/decode.py:798-898
+    sigma_hook(sigma NHWC) -> sigma: test aid for streams written by ANOTHER implementation of the transforms (the
+    reference on torch): its h_s rounds differently in the last bits, one differing CDF count on a coded symbol
+    desynchronises any arithmetic decoder, so such tests hand the writer's sigma to the CDF build (and check the own
+    sigma against it separately); everything else stays this decoder's own dataflow."""
     table, _ = O.balle_cdf_table(net['balle'])
     c_z, c_y = net['c_z'], net['c_y']
     npz = dim_z[0] * dim_z[1]
@@ -127,6 +131,8 @@ def cond_decode(net, sec_z, sec_y, in_shortcut, frame_type, dim_y, dim_z, idx_ra
     q_z = O.scatter_symbols(sym, npz, c_z, list(range(c_z))).reshape(1, dim_z[0], dim_z[1], c_z)
     z_hat = O.dequantize(q_z)
     mu, sigma = O.hyper_params(O.run_layer(net['h_s'], z_hat), c_y, dim_y[0], dim_y[1])
+    if sigma_hook is not None:
+        sigma = np.ascontiguousarray(sigma_hook(sigma), np.float32)
     npy = dim_y[0] * dim_y[1]
     n_maps = sec_y[0]
     maps = list(sec_y[1:1 + n_maps])
@@ -174,18 +180,21 @@ def encode_frame(model, cur, prev, nxt, frame_type, idx_rate=0.):
     return frame, _rec(cod_out, h, w, skip), data_dim
 
 
-def decode_frame(model, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0.):
-    """src/real_life/decode.py:455-580"""
+def decode_frame(model, frame_bytes, prev, nxt, frame_type, data_dim, idx_rate=0., sigma_hook=None):
+    """src/real_life/decode.py:455-580; sigma_hook(net name 'mofnet' / 'codecnet', sigma) -> sigma, see cond_decode"""
+    hook = (lambda name: (lambda s: sigma_hook(name, s))) if sigma_hook is not None else (lambda name: None)
     h, w = data_dim['x']
     sec = split_lp(frame_bytes, 0, 4)
     pred = skip = None
     if frame_type != FRAME_I:
         p444, n444 = to444(prev, h, w), to444(nxt if frame_type == FRAME_B else None, h, w)
         short_in = np.concatenate((p444, n444), axis=3) if frame_type == FRAME_B else None
-        mof_out = cond_decode(model['mof'], sec[0], sec[1], short_in, frame_type, data_dim['y'], data_dim['z'], idx_rate)
+        mof_out = cond_decode(model['mof'], sec[0], sec[1], short_in, frame_type, data_dim['y'], data_dim['z'], idx_rate,
+                              hook('mofnet'))
         wb = O.warp_blend(mof_out, p444, n444, h, w, frame_type, co=3)
         pred, skip = wb['pred'], wb['skip']
-    cod_out = cond_decode(model['cod'], sec[2], sec[3], pred, frame_type, data_dim['y'], data_dim['z'], idx_rate)
+    cod_out = cond_decode(model['cod'], sec[2], sec[3], pred, frame_type, data_dim['y'], data_dim['z'], idx_rate,
+                          hook('codecnet'))
     return _rec(cod_out, h, w, skip)
 
 
@@ -209,12 +218,13 @@ def encode_video(model, frames, gop_name, first=0, idx_rate=0.):
     return blob, recs[:n]
 
 
-def decode_video(model, blob):
+def decode_video(model, blob, sigma_hook=None):
+    """sigma_hook(absolute frame index, net name, sigma) -> sigma (test aid, see cond_decode)"""
     v = [int.from_bytes(blob[i:i + 2], 'big') for i in range(0, 18, 2)]
     data_dim = {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5])}
     nb_gop, first, last = v[6], v[7], v[8]
     out = []
-    for gb in split_lp(blob, 18, nb_gop):
+    for gi, gb in enumerate(split_lp(blob, 18, nb_gop)):
         ldp, chain, size = bool(gb[0]), int.from_bytes(gb[1:3], 'big'), int.from_bytes(gb[3:5], 'big')
         name = 'LDP_%d' % size if ldp else '%d_GOP_%d' % (chain, size)
         idx_rate = gb[5] / 16
@@ -223,6 +233,7 @@ def decode_video(model, blob):
         rec = {}
         for i in sorted(g, key=lambda i: g[i][3]):
             t, p, nx, _ = g[i]
-            rec[i] = decode_frame(model, fbytes[i], rec.get(p), rec.get(nx), t, data_dim, idx_rate)
+            fh = None if sigma_hook is None else (lambda name, s, idx=first + gi * len(g) + i: sigma_hook(idx, name, s))
+            rec[i] = decode_frame(model, fbytes[i], rec.get(p), rec.get(nx), t, data_dim, idx_rate, fh)
         out.extend(rec[i] for i in sorted(g))
     return out[:last - first + 1]

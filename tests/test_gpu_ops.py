@@ -238,6 +238,47 @@ def test_range_decode_from_windows(scale, oracle, cuda):
         assert (np.abs(q[..., maps]) > 32).any(), 'the slow path (symbol outside the window) must be exercised'
 
 
+@pytest.mark.parametrize('sigma', [1e-4, 0.3, 5.0, 148.0])
+def test_range_coder_forced_symbols(sigma, oracle, cuda):
+    """Deterministic visit of the decoder's corners: symbols 0, 1 (octet 0), 223 / 224 and 287 / 288 (either side of
+    the 64-entry window), 286, 510, 511 (octet 63: reads CDF entry 512 through lane 8) and 512 (value +256, torchac's
+    max_symbol, upper bound 2^16 packed as c_hi = 0) -- HIP bounds / bytes / symbols == oracle, from full rows and
+    from windows, at a sigma where everything sits in the window's tail and one where nothing does."""
+    from aivc_amd import ops
+    from test_rangecoder import forced_case
+    sig, q = forced_case(sigma, repeat=11)
+    n = q.size
+    want = (q.reshape(-1).astype(np.int32) + 256).astype(np.uint16)
+    b_ref = oracle.laplace_bounds(sig, q, [0])
+    b = ops.laplace_bounds(T(sig, cuda), T(q, cuda), [0])
+    eq(b, b_ref.view(np.int32))
+    ref_bytes = oracle.range_encode(b_ref)
+    out, lens, _ = ops.range_encode([b])
+    assert out.cpu().numpy()[:int(lens.cpu()[0])].tobytes() == ref_bytes
+    rows = ops.laplace_cdf_rows(T(sig, cuda), [0])
+    eq(rows, oracle.laplace_cdf_rows(sig, [0]).view(np.int16))
+    eq(ops.range_decode([ref_bytes], rows, [0], [n], [0])[0], want)
+    win, sp = ops.laplace_cdf_windows(T(sig, cuda), [0])
+    eq(ops.range_decode([ref_bytes], win, [0], [n], [0], sigma_pos=sp)[0], want)
+
+
+def test_range_coder_symbol_512_table_mode(oracle, cuda):
+    from aivc_amd import ops
+    from test_rangecoder import FORCED
+    rng = np.random.default_rng(5)
+    params = (rng.standard_normal((2, abi.BALLE_PARAMS)) * 0.8).astype(np.float32)
+    table, _ = oracle.balle_cdf_table(params)
+    qz = np.array(FORCED * 2, np.int16).reshape(1, 2, 5, 2)
+    b_ref = oracle.table_bounds(table, qz)
+    b = ops.table_bounds(T(table.view(np.int16), cuda), T(qz, cuda))
+    eq(b, b_ref.view(np.int32))
+    ref_bytes = oracle.range_encode(b_ref)
+    out, lens, _ = ops.range_encode([b])
+    assert out.cpu().numpy()[:int(lens.cpu()[0])].tobytes() == ref_bytes
+    sym = ops.range_decode([ref_bytes], T(table.view(np.int16), cuda), [0], [qz.size], [10])[0]
+    eq(ops.scatter_symbols(sym, 10, 2, [0, 1]), qz.reshape(10, 2))
+
+
 def test_range_coder_pmf_and_scatter(oracle, cuda):
     from aivc_amd import ops
     rng = np.random.default_rng(11)

@@ -139,7 +139,7 @@ def test_quantizer(cuda, golden):
     with torch.no_grad():
         y = Quantizer().eval()(torch.from_numpy(g['x']).to(cuda)).cpu().numpy().reshape(-1)
     ref = g['y'].reshape(-1)
-    ok = ref <= 255  # symbols are clamped to the coder's alphabet [-256, 255]
+    ok = ref <= 256  # values are clamped to the coder's alphabet [-256, 256] (symbols 0 .. 512)
     np.testing.assert_array_equal(y[ok], ref[ok])
 
 

@@ -141,10 +141,10 @@ def test_quantizer(oracle, golden):
     g = golden('quantizer_0')
     q, y = oracle.quantize_center(g['x'].reshape(1, 1, -1, 1))
     ref = g['y'].reshape(-1)
-    ok = ref <= 255  # the codec clamps symbols to [-256, 255] (the reference would make torchac raise)
-    np.testing.assert_array_equal(y.reshape(-1)[ok], ref[ok])  # half-to-even ties included
+    ok = ref <= 256  # the codec clamps values to [-256, 256] = symbols 0 .. 512, torchac's alphabet (beyond, the
+    np.testing.assert_array_equal(y.reshape(-1)[ok], ref[ok])  # reference makes torchac raise); half-to-even ties included
     np.testing.assert_array_equal(q.reshape(-1)[ok], ref[ok].astype(np.int16))
-    assert (y.reshape(-1)[~ok] == 255).all()
+    assert (y.reshape(-1)[~ok] == 256).all()
 
 
 @pytest.mark.parametrize('i', range(2))

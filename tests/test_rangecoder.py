@@ -99,3 +99,43 @@ def test_windows_twin_matches_full_rows(oracle):
     np.testing.assert_array_equal(win, rows[:, abi.CDF_WIN0:abi.CDF_WIN0 + abi.CDF_WIN])
     n = 2 * 35
     np.testing.assert_array_equal(oracle.range_decode_windows(payload, win, sp, n), oracle.range_decode(payload, rows, n))
+
+
+FORCED = [-256, -255, -33, -32, 30, 31, 32, 254, 255, 256]  # symbols 0, 1, 223, 224, 286, 287, 288, 510, 511, 512
+
+
+def forced_case(sigma, repeat=7):
+    """a stream that visits the edges of the decoder's window, of the alphabet and of the last octet, at one sigma"""
+    q = np.array((FORCED + [0, 1, -1]) * repeat, np.int16).reshape(1, 1, -1, 1)
+    return np.full(q.shape, sigma, np.float32), q
+
+
+def test_symbol_512_and_window_edges(oracle):
+    """value +256 = symbol 512 = torchac's max_symbol: upper bound 2^16 (packed as c_hi = 0); together with the
+    first / last entries of the decoder's 64-entry window and of the row.  Encoder == big-integer model, decoders
+    (full rows and windows) return the symbols."""
+    for sigma in (1e-4, 0.3, 5.0, 148.0):
+        sig, q = forced_case(sigma)
+        b = oracle.laplace_bounds(sig, q, [0])
+        want = (q.reshape(-1).astype(np.int32) + 256).astype(np.uint16)
+        assert ((b >> 16)[want == 512] == 0).all() and ((b >> 16)[want != 512] != 0).all()
+        pairs = [(int(v & 0xFFFF), int(v >> 16) or 0x10000) for v in b]
+        payload = oracle.range_encode(b)
+        assert payload == py_encode(pairs)
+        rows = oracle.laplace_cdf_rows(sig, [0])
+        np.testing.assert_array_equal(oracle.range_decode(payload, rows, len(want)), want)
+        win, sp = oracle.laplace_cdf_windows(sig, [0])
+        np.testing.assert_array_equal(oracle.range_decode_windows(payload, win, sp, len(want)), want)
+
+
+def test_symbol_512_table_mode(oracle):
+    from aivc_amd import abi
+    rng = np.random.default_rng(5)
+    params = (rng.standard_normal((2, abi.BALLE_PARAMS)) * 0.8).astype(np.float32)
+    table, _ = oracle.balle_cdf_table(params)
+    qz = np.array(FORCED * 2, np.int16).reshape(1, 2, 5, 2)
+    b = oracle.table_bounds(table, qz)
+    payload = oracle.range_encode(b)
+    assert payload == py_encode([(int(v & 0xFFFF), int(v >> 16) or 0x10000) for v in b])
+    sym = oracle.range_decode(payload, table, qz.size, plane=10)
+    np.testing.assert_array_equal(oracle.scatter_symbols(sym, 10, 2, [0, 1]), qz.reshape(10, 2))
