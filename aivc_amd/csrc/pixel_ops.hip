@@ -431,6 +431,7 @@ AIVC_EXPORT int aivc_yuv420_to_444(const float *y, const float *u, const float *
                                    aivc_stream_t stream) {
   if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
   if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
+  if (h > 65535 || n > 65535) return AIVC_ERR_UNSUPPORTED;  // grid y / z limits
   hipLaunchKernelGGL(yuv420_to_444_kernel<float>, dim3(cdiv((size_t)w, 1024), h, n), dim3(256), 0, to_stream(stream),
                      y, u, v, n, h, w, out, c_store, c_off, zero_pad);
   return check_launch("yuv420_to_444");
@@ -441,6 +442,7 @@ AIVC_EXPORT int aivc_yuv420u8_to_444(const uint8_t *y, const uint8_t *u, const u
                                      aivc_stream_t stream) {
   if (!y || !u || !v || !out || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
   if (c_off < 0 || c_off + 3 + (zero_pad ? 1 : 0) > c_store) return AIVC_ERR_ARG;
+  if (h > 65535 || n > 65535) return AIVC_ERR_UNSUPPORTED;  // grid y / z limits
   hipLaunchKernelGGL(yuv420_to_444_kernel<uint8_t>, dim3(cdiv((size_t)w, 1024), h, n), dim3(256), 0,
                      to_stream(stream), y, u, v, n, h, w, out, c_store, c_off, zero_pad);
   return check_launch("yuv420u8_to_444");

@@ -495,7 +495,8 @@ def laplace_cdf_rows(sigma, maps, out=None, row_off=0):
     if out is None:
         out = torch.empty((len(maps) * npix, abi.CDF_ROW), dtype=torch.int16, device=sigma.device)
         row_off = 0
-    _hbm_profiled('laplace_cdf_rows', len(maps) * npix * (4 + 2 * abi.CDF_ROW),
+    # fp64-VALU bound, not HBM bound: 514 expm1 evaluations per coded position; the profile counts CDF POINTS
+    _hbm_profiled('cdf_points:laplace_cdf_rows', len(maps) * npix * abi.LP,
                   lambda: call('aivc_laplace_cdf_rows', _p(sigma), npix, c, C.byref(ml),
                                out.data_ptr() + 2 * row_off * abi.CDF_ROW, _stream()))
     return out
@@ -513,7 +514,7 @@ def laplace_cdf_windows(sigma, maps, out=None, row_off=0):
                torch.empty(len(maps) * npix, dtype=torch.float32, device=sigma.device))
         row_off = 0
     win, sp = out
-    _hbm_profiled('laplace_cdf_rows', len(maps) * npix * (8 + 2 * abi.CDF_WIN),
+    _hbm_profiled('cdf_points:laplace_cdf_windows', len(maps) * npix * abi.CDF_WIN,
                   lambda: call('aivc_laplace_cdf_windows', _p(sigma), npix, c, C.byref(ml),
                                win.data_ptr() + 2 * row_off * abi.CDF_WIN, sp.data_ptr() + 4 * row_off, _stream()))
     return out

@@ -35,23 +35,18 @@ def unit_owner(u, world):
     return u % world
 
 
-def gather_gops(local_gops, dst=0):
+def gather_gops(local_gops, dst=0, device=None):
     """local_gops: list over ALL units with None for units coded elsewhere.  Returns the complete
-    list on rank `dst` (None on the others)."""
+    list on rank `dst` (None on the others).  Two tensor collectives (lengths, padded payload): no pickling."""
     rank, world = rank_world()
     if world == 1:
         return local_gops
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object(local_gops, gathered, dst=dst)
+    keys = list(range(len(local_gops)))
+    allb = gather_bytes_all({u: g for u, g in enumerate(local_gops) if g is not None}, keys, None, world, device)
     if rank != dst:
         return None
-    out = list(local_gops)
-    for r, lst in enumerate(gathered):
-        for u, g in enumerate(lst):
-            if g is not None:
-                out[u] = g
-    assert all(g is not None for g in out), 'a unit was coded by no rank'
-    return out
+    assert all(u in allb for u in keys), 'a unit was coded by no rank'
+    return [allb[u] for u in keys]
 
 
 def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, idx_rate=0.):
@@ -59,15 +54,20 @@ def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, id
     rank, world = rank_world()
     enc = frame_codec.encode_video(frames, gop_name, idx_starting_frame, idx_rate=idx_rate,
                                    unit_filter=lambda u: unit_owner(u, world) == rank)
-    gops = gather_gops(enc['gops'])
-    dims = [enc['data_dim']]
-    if world > 1:
-        all_dims = [None] * world
-        dist.all_gather_object(all_dims, enc['data_dim'])
-        dims = [d for d in all_dims if d is not None]
+    dev = getattr(frames[0]['y'], 'device', None)
+    dev = dev if isinstance(dev, torch.device) else None
+    gops = gather_gops(enc['gops'], device=dev)
+    data_dim = enc['data_dim']
+    if world > 1:  # ranks without a unit do not know the latent sizes: element-wise max of six int64
+        cdev = _comm_device(None, dev)
+        v = [-1] * 6 if data_dim is None else [*data_dim['x'], *data_dim['y'], *data_dim['z']]
+        t = torch.tensor(v, dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        v = [int(x) for x in t.cpu()]
+        data_dim = {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
     if gops is None:
         return None
-    enc = dict(enc, gops=gops, data_dim=dims[0])
+    enc = dict(enc, gops=gops, data_dim=data_dim)
     return frame_codec.assemble_video(enc)
 
 
@@ -77,19 +77,46 @@ def decode_video_sharded(frame_codec, blob, device=None):
     rank, world = rank_world()
     frames, data_dim, first, last = frame_codec.decode_video(
         blob, device, unit_filter=lambda u: unit_owner(u, world) == rank)
-    local = [None if f is None else {k: f[k].cpu() for k in 'yuv'} for f in frames]
     if world == 1:
-        return local
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(local, gathered, dst=0)
+        return [None if f is None else {k: f[k].cpu() for k in 'yuv'} for f in frames]
+    # one all_gather of the 8-bit planes (every rank sends `per` frame slots of h*w + 2*hc*wc bytes, its decoded
+    # frames first): a tensor collective on the device under RCCL, no pickling
+    h, w = data_dim['x']
+    hc, wc = (h + 1) // 2, (w + 1) // 2
+    fsz = h * w + 2 * hc * wc
+    owner = [None] * len(frames)  # (rank, slot) of every frame: units are dealt round-robin, known everywhere
+    counts = [0] * world
+    unit = len(frames_per_unit(blob))
+    for i in range(len(frames)):
+        r = unit_owner(i // unit, world)
+        owner[i] = (r, counts[r])
+        counts[r] += 1
+    per = max(counts)
+    dev = next(f['y'].device for f in frames if f is not None) if any(f is not None for f in frames) else device
+    cdev = _comm_device(None, dev)
+    send = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
+    mine = [f for f in frames if f is not None]
+    if mine:
+        torch.cat([f[k].reshape(-1).to(cdev) for f in mine for k in 'yuv'], out=send.view(-1)[:len(mine) * fsz])
+    recv = torch.empty((world * per, fsz), dtype=torch.uint8, device=cdev)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
     if rank != 0:
         return None
-    out = list(local)
-    for lst in gathered:
-        for i, f in enumerate(lst):
-            if f is not None:
-                out[i] = f
+    recv = recv.cpu()
+    out = []
+    for r, slot in owner:
+        row = recv[r * per + slot]
+        out.append({'y': row[:h * w].view(1, h, w), 'u': row[h * w:h * w + hc * wc].view(1, hc, wc),
+                    'v': row[h * w + hc * wc:].view(1, hc, wc)})
     return out
+
+
+def frames_per_unit(blob):
+    """display-order frame names of one intra-period unit of the video `blob` (all its units share a structure)"""
+    from .func_util.GOP_structure import generate_gop_struct
+    from .real_life import cat_binary_files as container
+    _, _, _, gops = container.unpack_video(blob)
+    return generate_gop_struct(container.unpack_gop(gops[0])[0])
 
 
 # ---- one clip over all GPUs: unit groups x temporal-layer sharding (SURVEY.md 8e) ---------------------------
@@ -109,9 +136,58 @@ def _comm_device(group=None, device=None):
     return torch.device('cpu')
 
 
+def gather_bytes_all(mine, keys, group, n_ranks, device=None):
+    """mine: {key: bytes} held by this rank; keys: ordered list of all keys (same on all ranks).
+    -> {key: bytes} complete on every rank of `group` (None: all ranks).  Two tensor collectives: lengths, padded
+    payload -- uint8 / int64 tensors on the device under RCCL, host memory under gloo; no pickling."""
+    cdev = _comm_device(group, device)
+    lens = torch.tensor([len(mine[k]) if k in mine else -1 for k in keys], dtype=torch.int64, device=cdev)
+    all_lens = torch.empty((n_ranks, len(keys)), dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(all_lens.view(-1), lens, group=group)
+    all_lens = all_lens.cpu()
+    totals = all_lens.clamp_min(0).sum(dim=1)
+    cap = max(int(totals.max()), 1)
+    payload = bytearray()
+    for k in keys:
+        if k in mine:
+            payload += mine[k]
+    buf = torch.zeros(cap, dtype=torch.uint8)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(payload, dtype=torch.uint8)
+    buf = buf.to(cdev)
+    recv = torch.empty((n_ranks, cap), dtype=torch.uint8, device=cdev)
+    dist.all_gather_into_tensor(recv.view(-1), buf, group=group)
+    recv = recv.cpu().numpy()
+    out = {}
+    for r in range(n_ranks):
+        pos = 0
+        for j, k in enumerate(keys):
+            n = int(all_lens[r, j])
+            if n >= 0:
+                out.setdefault(k, recv[r, pos:pos + n].tobytes())
+                pos += n
+    return out
+
+
+_SHARDS = {}
+
+
+def clip_shard(n_units, device=None):
+    """The ClipShard of (n_units, world, device), built once per process: every construction calls dist.new_group
+    per unit group, which under RCCL allocates a communicator that is never freed -- a service coding many clips
+    must not build one per clip.  COLLECTIVE on first use for a key: every rank has to make the same first call."""
+    _, world = rank_world()
+    key = (int(n_units), world, None if device is None else str(device), dist.get_backend() if is_dist() else None)
+    sh = _SHARDS.get(key)
+    if sh is None:
+        sh = _SHARDS[key] = ClipShard(n_units, device)
+    return sh
+
+
 class ClipShard:
-    """Partition of one clip's work over the ranks.  Collective: every rank must construct it (sub-groups are
-    created with dist.new_group in the same order everywhere)."""
+    """Partition of one clip's work over the ranks.  Construction is a COLLECTIVE call: every rank must construct
+    it (sub-groups are created with dist.new_group in the same order everywhere); prefer clip_shard(), which builds
+    one per (n_units, world, device) and keeps it."""
 
     def __init__(self, n_units, device=None):
         self.rank, self.world = rank_world()
@@ -132,6 +208,7 @@ class ClipShard:
                 if g == self.group_id:
                     self.pg = pg
         self.leaders = [g * self.R for g in range(self.G)]
+        self._bufs = {}  # persistent exchange buffers, (slots, frame bytes, device) -> (send, recv)
 
     # ---- who codes what ---------------------------------------------------------------------------------
     def mine(self, items):
@@ -144,14 +221,24 @@ class ClipShard:
         if self.R == 1:
             return my_recs
         cdev = _comm_device(self.pg, device)
-        per = (len(items) + self.R - 1) // self.R  # every rank sends `per` frames (zero padded)
+        per = (len(items) + self.R - 1) // self.R  # every rank sends `per` frame slots (unused ones: stale bytes)
         hc, wc = (h + 1) // 2, (w + 1) // 2
         fsz = h * w + 2 * hc * wc
-        send = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
-        for i, r in enumerate(my_recs):
-            send[i] = torch.cat([r[k].reshape(-1) for k in 'yuv']).to(cdev)
+        # the send side is persistent (one buffer per shape); the receive side is allocated per call: the frames
+        # handed out below are views of it and live as references for the rest of the unit
+        key = (per, fsz, str(cdev))
+        send = self._bufs.get(key)
+        if send is None:
+            send = self._bufs[key] = torch.zeros((per, fsz), dtype=torch.uint8, device=cdev)
+        if my_recs:  # ONE launch packs every plane of this rank's frames (was a cat + copy per frame)
+            flat = [r[k].reshape(-1) if r[k].device == cdev else r[k].reshape(-1).to(cdev) for r in my_recs for k in 'yuv']
+            torch.cat(flat, out=send.view(-1)[:len(my_recs) * fsz])
         recv = torch.empty((self.R * per, fsz), dtype=torch.uint8, device=cdev)
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.pg)  # flat: gloo wants 1-D
+        # asynchronous: under RCCL the gather runs on the communicator's own stream (it waits for the packing on
+        # the current stream, nothing else does: the entropy coder's side streams keep running); the current stream
+        # joins it at work.wait() -- the frames are the references of the very next level, so that is right away
+        work = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.pg, async_op=True)  # flat: gloo wants 1-D
+        work.wait()
         recv = recv.to(device)
         out = [None] * len(items)
         for j in range(len(items)):
@@ -161,36 +248,7 @@ class ClipShard:
         return out
 
     def _gather_bytes(self, mine, keys, group, n_ranks, device=None):
-        """mine: {key: bytes} held by this rank; keys: ordered list of all keys (same on all ranks).
-        -> {key: bytes} complete on every rank of `group`.  Two tensor collectives: lengths, padded payload."""
-        cdev = _comm_device(group, device or self.device)
-        lens = torch.tensor([len(mine[k]) if k in mine else -1 for k in keys], dtype=torch.int64, device=cdev)
-        all_lens = torch.empty((n_ranks, len(keys)), dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(all_lens.view(-1), lens, group=group)
-        all_lens = all_lens.cpu()
-        totals = all_lens.clamp_min(0).sum(dim=1)
-        cap = max(int(totals.max()), 1)
-        payload = bytearray()
-        for k in keys:
-            if k in mine:
-                payload += mine[k]
-        buf = torch.zeros(cap, dtype=torch.uint8)
-        if payload:
-            buf[:len(payload)] = torch.frombuffer(payload, dtype=torch.uint8)
-        buf = buf.to(cdev)
-        recv = torch.empty((n_ranks, cap), dtype=torch.uint8, device=cdev)
-        dist.all_gather_into_tensor(recv.view(-1), buf, group=group)
-        recv = recv.cpu().numpy()
-        out = {}
-        for r in range(n_ranks):
-            pos = 0
-            for j, k in enumerate(keys):
-                n = int(all_lens[r, j])
-                if n >= 0:
-                    out.setdefault(k, recv[r, pos:pos + n].tobytes())
-                    pos += n
-        return out
-
+        return gather_bytes_all(mine, keys, group, n_ranks, device or self.device)
     def gather_bytes(self, mine, keys):
         """frame bitstreams inside the group"""
         if self.R == 1:
@@ -231,7 +289,7 @@ class ClipShard:
 def encode_clip(frame_codec, units, gop_name, idx_rate=0., shard=None):
     """Strong scaling: ONE clip (list of intra-period units, every rank passes the same frames) over all ranks.
     -> ([GOP record per unit], data_dim) on every rank; bytes identical to frame_codec.encode_units(units)."""
-    shard = shard or ClipShard(len(units), units[0][0]['y'].device)
+    shard = shard or clip_shard(len(units), units[0][0]['y'].device)
     mine = {}
     data_dim = None
     if shard.units:
@@ -243,7 +301,7 @@ def encode_clip(frame_codec, units, gop_name, idx_rate=0., shard=None):
 def decode_clip(frame_codec, gop_blobs, data_dim, device=None, shard=None):
     """-> {unit: [reconstructions in display order]} for the units of this rank's group (the frames stay on the
     GPUs that decoded them; every rank of a group holds all frames of the group's units)."""
-    shard = shard or ClipShard(len(gop_blobs), device)
+    shard = shard or clip_shard(len(gop_blobs), device)
     if not shard.units:
         return {}
     recs = frame_codec.decode_units([gop_blobs[u] for u in shard.units], data_dim, device, shard=shard)
@@ -327,4 +385,4 @@ def decode_units_level_sharded(frame_codec, gop_blobs, data_dim, device=None, sh
 
 def _whole_world_shard(device):
     """all ranks form ONE group (level sharding only): ClipShard of a single unit"""
-    return ClipShard(1, device)
+    return clip_shard(1, device)

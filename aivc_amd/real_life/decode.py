@@ -121,32 +121,45 @@ def debug_dir(bitstream_path):
     return bitstream_path + '.debug'
 
 
-def plane_md5(plane):
+def plane_md5(plane, kind=None):
     """Digest flag_bitstream_debug compares per plane.  The reference hashes the PNG FILE it saved for the plane
     (save_yuv_separately -> to_pil_image(mode='L').save, src/func_util/img_processing.py:290-302; compare at
     src/real_life/decode.py:304-326): the same file is produced here in memory with PIL, so the .md5 files
     interoperate with a reference decoder / encoder running the same Pillow + zlib (the PNG byte stream depends
-    on them; pinned by tests/golden/decoder_*.npz `pngmd5_*`).  Without PIL: digest of the raw 8-bit plane."""
+    on them; pinned by tests/golden/decoder_*.npz `pngmd5_*`).  kind='raw': digest of the raw 8-bit plane,
+    independent of Pillow / zlib; kind=None picks 'png' when Pillow is importable."""
     import hashlib
     a = plane.cpu().numpy() if isinstance(plane, torch.Tensor) else np.asarray(plane)
     a = np.ascontiguousarray(a.reshape(a.shape[-2], a.shape[-1]))
-    try:
-        import io
-        from PIL import Image
-    except ImportError:
+    if kind is None:
+        kind = digest_kind()
+    if kind == 'raw':
         return hashlib.md5(a.tobytes()).hexdigest()
+    import io
+    from PIL import Image
     buf = io.BytesIO()
     Image.fromarray(a, 'L').save(buf, format='PNG')
     return hashlib.md5(buf.getvalue()).hexdigest()
 
 
+def digest_kind():
+    try:
+        import PIL  # noqa: F401
+        return 'png'
+    except ImportError:
+        return 'raw'
+
+
 def write_debug_md5(frames, first, directory):
-    """encoder side of flag_bitstream_debug: '<idx>_<c>.md5' per reconstructed plane (see plane_md5)."""
+    """encoder side of flag_bitstream_debug: '<idx>_<c>.md5' per reconstructed plane (see plane_md5).  A bare
+    32-digit digest is the md5 of the PNG file, as in the reference; where Pillow is missing the file says
+    'raw:<digest>' so that the decoder compares like with like whatever ITS environment."""
     os.makedirs(directory, exist_ok=True)
+    kind = digest_kind()
     for i, fr in enumerate(frames):
         for c in 'yuv':
             with open(os.path.join(directory, '%d_%s.md5' % (first + i, c)), 'w') as f:
-                f.write(plane_md5(fr[c]))
+                f.write(('raw:' if kind == 'raw' else '') + plane_md5(fr[c], kind))
 
 
 def check_debug_md5(frames, first, directory):
@@ -158,7 +171,10 @@ def check_debug_md5(frames, first, directory):
             with open(os.path.join(directory, name + '.md5')) as f:
                 encoder_md5 = f.read().strip()
             msg = name + ': '
-            if encoder_md5 != plane_md5(fr[c]):
+            kind = 'png'
+            if encoder_md5.startswith('raw:'):
+                kind, encoder_md5 = 'raw', encoder_md5[4:]
+            if encoder_md5 != plane_md5(fr[c], kind):  # (a 'png' digest without Pillow here raises: no silent fallback)
                 bad += 1
                 msg += '\n' + '-' * 80 + '\n' + 'Incorrect reconstruction!\n' + '-' * 80 + '\n'
             else:

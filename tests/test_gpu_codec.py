@@ -128,6 +128,54 @@ def test_config5_2160p(cuda):
     _closed_loop(cuda, 3840, 2160, 3, '1_GOP_2', max_batch=2)
 
 
+def test_config4_one_full_gop32_unit_1080p(cuda):
+    """BASELINE configs[3]'s coding structure itself: one whole 33-frame `1_GOP_32` unit (I, P, 31 hierarchical B
+    over 7 dependency levels, level widths 1, 1, 1, 2, 4, 8, 16) at 1920x1080 with the bench's batch size --
+    decoder == encoder reconstruction for every frame, container idempotent."""
+    blob, enc, dec, frames = _closed_loop(cuda, 1920, 1080, 33, '1_GOP_32', max_batch=16)
+    assert enc['nb_gop'] == 1 and len(dec) == 33
+
+
+def test_config5_2160p_high_rate(cuda):
+    """BASELINE configs[4] says "ms_ssim-2 (high rate)": every one of the 64 y maps of both networks non-zero
+    (2.1 M coded symbols per latent at 3840x2160) -- closed loop, and the y sections do list all 64 maps."""
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from aivc_amd.real_life import cat_binary_files as cont
+    from aivc_amd.real_life.bitstream import split_sections
+    model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+    synth.calibrate_operating_point(model, cuda, active_y=(64, 64))
+    blob, enc, dec, frames = _closed_loop(cuda, 3840, 2160, 3, '1_GOP_2', model=model, max_batch=2)
+    _, _, _, gops = cont.unpack_video(blob)
+    for i, fr in enumerate(cont.unpack_gop(gops[0])[2]):
+        s = split_sections(fr)
+        assert s[3][0] == 64 and (i == 0 or s[1][0] == 64), i
+
+
+def test_default_widths_hip_equals_oracle_416x240_gop4(cuda):
+    """HIP == CPU oracle, bytes and frames, with the DEFAULT-width model (64 / 128 channels: the MFMA tile
+    shapes, fused GDN / tail / gate kernels and conv_images of the bench) on a 416x240 `1_GOP_4` clip -- the
+    default-width parity the bench asserts on its I+P+B triple, here inside the GPU test tier."""
+    from aivc_amd import synth
+    from aivc_amd.models import arch
+    from oracle import codec as ocodec
+    from oracle import spec as ospec
+    model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+    synth.calibrate_operating_point(model, cuda)
+    frames = synth.synthetic_video(416, 240, 5, seed=9)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        enc = fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_4')
+        blob = fc.assemble_video(enc)
+        dec, _, _, _ = fc.decode_video(blob, cuda)
+    spec = ospec.export_model(model)
+    ref_blob, ref_rec = ocodec.encode_video(spec, frames, '1_GOP_4')
+    assert blob == ref_blob
+    for d, r in zip(dec, ref_rec):
+        for k in 'yuv':
+            np.testing.assert_array_equal(d[k][0].cpu().numpy(), r[k])
+
+
 def test_odd_frame_size_and_padding_of_last_unit(cuda):
     # 7 frames with a 5-frame unit: the last unit is padded by repeating the last frame, the padded
     # frames are dropped again by the decoder (src/model_mngt/model_management.py:148-153)

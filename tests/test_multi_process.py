@@ -40,6 +40,21 @@ class OracleUnitCodec:
         from aivc_amd.codec import FrameCodec
         return FrameCodec.assemble_video(enc)
 
+    def decode_video(self, blob, device=None, unit_filter=None):
+        """FrameCodec.decode_video's contract: frames of units filtered out are None"""
+        from aivc_amd.real_life import cat_binary_files as container
+        from oracle import codec as oc
+        data_dim, first, last, gops = container.unpack_video(blob)
+        frames = []
+        for u, g in enumerate(gops):
+            n_unit = len(container.unpack_gop(g)[2])
+            if unit_filter is not None and not unit_filter(u):
+                frames += [None] * n_unit
+                continue
+            one = oc.video_header(data_dim, 1, 0, n_unit - 1) + oc.lp(g)
+            frames += [{k: torch.from_numpy(f[k])[None] for k in 'yuv'} for f in oc.decode_video(self.spec, one)]
+        return frames[:last - first + 1], data_dim, first, last
+
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -59,10 +74,17 @@ def _worker(rank, world, port, q):
     codec = OracleUnitCodec(ospec.export_model(model))
     blob = parallel.encode_video_sharded(codec, frames, 'LDP_2')
     owners = [parallel.unit_owner(u, world) for u in range(3)]
+    # decode: every rank holds the bitstream (broadcast from rank 0 for the test), decodes its units, rank 0 gets all
+    n = torch.tensor([len(blob) if rank == 0 else 0])
+    dist.broadcast(n, 0)
+    buf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone() if rank == 0 else torch.empty(int(n), dtype=torch.uint8)
+    dist.broadcast(buf, 0)
+    dec = parallel.decode_video_sharded(codec, buf.numpy().tobytes(), torch.device('cpu'))
+    dec = None if dec is None else [{k: f[k][0].numpy().copy() for k in 'yuv'} for f in dec]
     if rank == 0:
-        q.put((blob, owners, float(sum(p.double().sum() for p in model.parameters()))))
+        q.put((blob, owners, float(sum(p.double().sum() for p in model.parameters())), dec))
     else:
-        q.put((None, owners, float(sum(p.double().sum() for p in model.parameters()))))
+        q.put((None, owners, float(sum(p.double().sum() for p in model.parameters())), dec))
     dist.destroy_process_group()
 
 
@@ -90,8 +112,12 @@ def test_two_rank_sharding_matches_single_process(oracle):
     from oracle import codec as oc
     from oracle import spec as ospec
     model = synth.make_model(arch.TINY_WIDTHS, seed=100)
-    ref, _ = oc.encode_video(ospec.export_model(model), synth.synthetic_video(48, 32, 7, seed=2), 'LDP_2')
+    ref, ref_recs = oc.encode_video(ospec.export_model(model), synth.synthetic_video(48, 32, 7, seed=2), 'LDP_2')
     assert blobs[0] == ref
+    decs = [r[3] for r in res if r[3] is not None]
+    assert len(decs) == 1 and len(decs[0]) == 7  # rank 0 only; frames of both ranks' units, padding removed
+    for d, r in zip(decs[0], ref_recs):
+        assert all(np.array_equal(d[k], r[k]) for k in 'yuv')
 
 
 class OracleFrameCodec:
