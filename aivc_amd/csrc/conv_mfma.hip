@@ -61,7 +61,13 @@ __device__ unsigned long long aivc_dbg_t[8 * 8192];
 #endif
 constexpr int TAIL_N = 128;  // output channels of the fused 1x1 tail (the bottleneck blocks: 64 -> 128)
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false>
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): LDS destination = lds_dst (wave-uniform, through M0) +
+// lane * 16, source = base (SGPR pair) + voff (per-lane byte offset).  Counts on vmcnt like a load; no VGPR result.
+__device__ __forceinline__ void glds16(const float *base, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false>
 __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1)))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(!TAIL || (MODE == AIVC_MODE_CONV && !FUSE && FASTK && BN == 64 && BN % BK == 0), "fused tail: conv, c_out 64");
@@ -347,6 +353,146 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
   };
   auto mma_tile = [&](floatx16 (&c)[TM][TN], bool skip) { mma_octs(c, 0, 0, OCT, skip); };
 
+  if constexpr (GLDS) {
+    // ---- LDS-DMA K loop (round 3) -----------------------------------------------------------------------------
+    // Operand tiles go global -> LDS by global_load_lds_dwordx4: no staging registers, no ds_write pass, no per-K-tile
+    // address arithmetic on the vector unit (the K-tile's channel offset sits in the scalar base, the per-lane pixel
+    // offset changes only with the kernel tap).  What that buys on this part, where every issued instruction costs
+    // the fp32 matrix pipe ~4.4 cycles and the clock is power-limited (tools/glds_probe.hip: 2.14 GHz with register
+    // staging, 2.23 GHz with LDS-DMA at the same tile): fewer instructions per MFMA and a higher clock.
+    //   LDS image   two stages of (BM + BN) rows x 128 bytes, UNPADDED (a DMA writes 64 x 16 contiguous bytes: 8
+    //               rows), XOR-swizzled instead: the 16-byte slot s of row R holds data chunk s ^ swz(R),
+    //               swz(R) = (R & 7) ^ ((R >> 3) & 3) -- applied on the SOURCE address of the DMA and on the
+    //               fragment reads alike; conflict-free ds_read_b128 for 8- and 16-lane groups.
+    //   schedule    tile kt+1 is in flight during the MFMAs of tile kt; the wait for it, the one barrier per K-tile
+    //               and the first fragment reads of tile kt+1 sit in the shadow of tile kt's last 16 MFMAs, after
+    //               which this stage is refilled with tile kt+2 (its last readers passed the barrier with their
+    //               fragments in registers).  Accumulation order unchanged: octets ascending, AIVC_K_ORDER inside.
+    static_assert(FASTK && MODE == AIVC_MODE_CONV, "LDS-DMA loop: conv with c_in % 32 == 0");
+    constexpr int ROWB = BK * 4, STAGE_B = (BM + BN) * ROWB, GA = BM / 32, GB = BN / 32;
+    char *ring = reinterpret_cast<char *>(smem);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+    const int l3 = lane >> 3;
+    const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ l3 ^ wave) << 4);  // this lane's data chunk (bytes) in a K row
+    int g_by[GA], g_bx[GA];
+    uint32_t g_nb[GA], g_avo[GA], g_bvo[GB];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+      int m = m0 + 32 * j + 8 * wave + l3;
+      m = m < M ? m : M - 1;
+      const int ox = m % p.w_out, t = m / p.w_out;
+      g_bx[j] = ox * p.stride - p.pad;
+      g_by[j] = (t % p.h_out) * p.stride - p.pad;
+      g_nb[j] = (uint32_t)(t / p.h_out) * (uint32_t)(H * W);
+      g_avo[j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      const int co = n0 + 32 * j + 8 * wave + l3;
+      const int coc = co < Cout ? co : Cout - 1;  // rows beyond c_out are never stored
+      g_bvo[j] = (uint32_t)coc * (uint32_t)(K * 4) + chunk_b;
+    }
+    const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+    auto issue_tile = [&](int kt, int stage) {
+      const int kbase = kt * BK;
+      int ty, tx, ci0;
+      tap_of(kbase, ty, tx, ci0);  // wave-uniform
+      if (ci0 == 0) {              // new kernel tap: the per-lane pixel offsets change
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+          const int iy = max(min(g_by[j] + ty, H - 1), 0), ix = max(min(g_bx[j] + tx, W - 1), 0);
+          g_avo[j] = (g_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)(Cin * 4) + chunk_b;
+        }
+      }
+      const float *ab = p.x + ci0, *bb = p.w + kbase;
+      const uint32_t dst = wdst + (uint32_t)stage * STAGE_B;
+#pragma unroll
+      for (int j = 0; j < GA; ++j) glds16(ab, g_avo[j], dst + j * 4096);
+#pragma unroll
+      for (int j = 0; j < GB; ++j) glds16(bb, g_bvo[j], dst + BM * ROWB + j * 4096);
+    };
+    // fragment reads: lane reads row (lane & 31) of its 32-row blocks, data chunk 2 o + (lane >> 5)
+    const int sw = (lane & 7) ^ ((lane >> 3) & 3);
+    const char *a_rd[OCT], *b_rd[OCT];
+#pragma unroll
+    for (int o = 0; o < OCT; ++o) {
+      const int off = ((2 * o + (lane >> 5)) ^ sw) << 4;
+      a_rd[o] = ring + (wm * TM * 32 + (lane & 31)) * ROWB + off;
+      b_rd[o] = ring + BM * ROWB + (wn * TN * 32 + (lane & 31)) * ROWB + off;
+    }
+    float4 fa[2][TM], fb[2][TN];
+    auto read_oct = [&](auto SET, auto STAGE, auto O) {
+      constexpr int set = decltype(SET)::value, stage = decltype(STAGE)::value, o = decltype(O)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(a_rd[o] + stage * STAGE_B + i * 32 * ROWB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[set][j] = *reinterpret_cast<const float4 *>(b_rd[o] + stage * STAGE_B + j * 32 * ROWB);
+    };
+    auto mfma_step = [&](auto SET, auto S) {
+      constexpr int set = decltype(SET)::value, st = decltype(S)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float av = st == 0 ? fa[set][i].x : (st == 1 ? fa[set][i].y : (st == 2 ? fa[set][i].z : fa[set][i].w));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float bv = st == 0 ? fb[set][j].x : (st == 1 ? fb[set][j].y : (st == 2 ? fb[set][j].z : fb[set][j].w));
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+        }
+      }
+    };
+    using std::integral_constant;
+    using I0 = integral_constant<int, 0>;
+    using I1 = integral_constant<int, 1>;
+    using I2 = integral_constant<int, 2>;
+    using I3 = integral_constant<int, 3>;
+#define AIVC_SB() __builtin_amdgcn_sched_barrier(0)
+    auto oct_mfmas = [&](auto SET) { mfma_step(SET, I0{}); mfma_step(SET, I1{}); mfma_step(SET, I2{}); mfma_step(SET, I3{}); };
+    auto body = [&](auto STAGE, int kt) {
+      constexpr int stage = decltype(STAGE)::value;
+      using NEXT = integral_constant<int, 1 - stage>;
+      read_oct(I1{}, STAGE, I1{});
+      AIVC_SB();
+      oct_mfmas(I0{});
+      AIVC_SB();
+      read_oct(I0{}, STAGE, I2{});
+      AIVC_SB();
+      oct_mfmas(I1{});
+      AIVC_SB();
+      read_oct(I1{}, STAGE, I3{});
+      AIVC_SB();
+      oct_mfmas(I0{});
+      AIVC_SB();
+      mfma_step(I1{}, I0{});
+      AIVC_SB();
+      if (kt + 1 < nkt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of tile kt + 1 have landed ...
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; everybody is done reading this stage
+      }
+      AIVC_SB();
+      mfma_step(I1{}, I1{});
+      AIVC_SB();
+      if (kt + 1 < nkt) read_oct(I0{}, NEXT{}, I0{});
+      AIVC_SB();
+      mfma_step(I1{}, I2{});
+      AIVC_SB();
+      if (kt + 2 < nkt) issue_tile(kt + 2, stage);
+      AIVC_SB();
+      mfma_step(I1{}, I3{});
+      AIVC_SB();
+    };
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nkt > 1) issue_tile(1, 1);
+    read_oct(I0{}, I0{}, I0{});
+    for (int kt = 0; kt < nkt; kt += 2) {
+      if (kt == 2) { DBG_T(2); }
+      body(I0{}, kt);
+      if (kt + 1 < nkt) body(I1{}, kt + 1);
+    }
+#undef AIVC_SB
+    __syncthreads();  // the ring is reused (padded layout) by the fused phases below
+  } else {
   load_tile(0);
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt == 1) { DBG_T(2); }
@@ -356,6 +502,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     __syncthreads();
     if (kt + 1 < nkt) load_tile(kt + 1);
     mma_tile(acc, skip3);
+  }
   }
 
 
@@ -869,7 +1016,7 @@ extern "C" __attribute__((visibility("default"))) int aivc_dbg_dump(unsigned lon
 }
 #endif
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false>
 static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   MfmaArgs a;
@@ -888,13 +1035,24 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
     a.first_round = f ? atoi(f) : 512;
   }
 #endif
-  const size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL>), grid, dim3(256), lds, s, a);
+  size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
+  if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
+}
+
+// LDS-DMA K loop: conv with c_in % 32 == 0 on the tiles it is instantiated for; per-lane BYTE offsets are 32 bits
+static bool use_glds(const aivc_conv_params &p) {
+  static const int off = getenv("AIVC_NO_GLDS") ? 1 : 0;  // tuning aid: the register-staged loop everywhere
+  if (off || p.mode != AIVC_MODE_CONV || p.c_in % BK != 0) return false;
+  return (uint64_t)p.n * p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFFFull && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 4ull < 0xFFFFFFFFull;
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
 static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
+  if constexpr (MODE == AIVC_MODE_CONV && WM == 2 && WN == 2 && TM == 2 && (TN == 2 || TN == 1)) {
+    if (use_glds(p)) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true, false, true>(p, s);
+  }
   if (p.c_in % BK == 0) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true>(p, s);
   return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, false>(p, s);
 }
@@ -1013,6 +1171,7 @@ bool conv2d_mfma_supported(const aivc_conv_params &p) {
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
   if (p.tail_c_out) {
     if (!conv2d_mfma_tail_supported(p)) return AIVC_ERR_UNSUPPORTED;
+    if (use_glds(p)) return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true, true>(p, s);
     return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true>(p, s);
   }
   switch (p.mode) {

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Pretty-print the JSON line of bench.py read from stdin."""
+"""Pretty-print the JSON line of bench.py (file argument, else stdin)."""
 import json
 import sys
-for line in sys.stdin:
+for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     line = line.strip()
     if not line.startswith('{'):
         continue
