@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     //               and the first fragment reads of tile kt+1 sit in the shadow of tile kt's last 16 MFMAs, after
     //               which this stage is refilled with tile kt+2 (its last readers passed the barrier with their
     //               fragments in registers).  Accumulation order unchanged: octets ascending, AIVC_K_ORDER inside.
-    static_assert(FASTK && MODE == AIVC_MODE_CONV, "LDS-DMA loop: conv with c_in % 32 == 0");
+    //   transposed  out-of-image taps (zero fill): such lanes take no part in the DMA and write 16 zero bytes to their
+    //   conv        slot instead; tiles away from the image border never see the branch (wave-uniform test per tap).
+    static_assert(FASTK && !GDN, "LDS-DMA loop: conv / transposed conv with c_in % 32 == 0");
     constexpr int ROWB = BK * 4, STAGE_B = (BM + BN) * ROWB, GA = BM / 32, GB = BN / 32;
     char *ring = reinterpret_cast<char *>(smem);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
@@ -376,21 +378,31 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ l3 ^ wave) << 4);  // this lane's data chunk (bytes) in a K row
     int g_by[GA], g_bx[GA];
     uint32_t g_nb[GA], g_avo[GA], g_bvo[GB];
+    bool g_in[GA];
+    bool tap_all_in = true;  // wave-uniform: no lane of this wave samples outside the image at the current tap
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
       int m = m0 + 32 * j + 8 * wave + l3;
       m = m < M ? m : M - 1;
-      const int ox = m % p.w_out, t = m / p.w_out;
-      g_bx[j] = ox * p.stride - p.pad;
-      g_by[j] = (t % p.h_out) * p.stride - p.pad;
-      g_nb[j] = (uint32_t)(t / p.h_out) * (uint32_t)(H * W);
+      if (TCONV) {
+        const int t = m / W;
+        g_bx[j] = m % W;
+        g_by[j] = t % H;
+        g_nb[j] = (uint32_t)(t / H) * (uint32_t)(H * W);
+      } else {
+        const int ox = m % p.w_out, t = m / p.w_out;
+        g_bx[j] = ox * p.stride - p.pad;
+        g_by[j] = (t % p.h_out) * p.stride - p.pad;
+        g_nb[j] = (uint32_t)(t / p.h_out) * (uint32_t)(H * W);
+      }
       g_avo[j] = 0;
+      g_in[j] = true;
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
       const int co = n0 + 32 * j + 8 * wave + l3;
       const int coc = co < Cout ? co : Cout - 1;  // rows beyond c_out are never stored
-      g_bvo[j] = (uint32_t)coc * (uint32_t)(K * 4) + chunk_b;
+      g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + chunk_b;
     }
     const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
     auto issue_tile = [&](int kt, int stage) {
@@ -398,16 +410,34 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       int ty, tx, ci0;
       tap_of(kbase, ty, tx, ci0);  // wave-uniform
       if (ci0 == 0) {              // new kernel tap: the per-lane pixel offsets change
+        const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
+        bool all_in = true;
 #pragma unroll
         for (int j = 0; j < GA; ++j) {
-          const int iy = max(min(g_by[j] + ty, H - 1), 0), ix = max(min(g_bx[j] + tx, W - 1), 0);
+          int iy = g_by[j] + (TCONV ? dyt : ty), ix = g_bx[j] + (TCONV ? dxt : tx);
+          if (TCONV) {
+            g_in[j] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            all_in = all_in && g_in[j];
+          }
+          iy = max(min(iy, H - 1), 0);
+          ix = max(min(ix, W - 1), 0);
           g_avo[j] = (g_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)(Cin * 4) + chunk_b;
         }
+        if (TCONV) tap_all_in = __builtin_amdgcn_ballot_w64(all_in) == ~0ull;
       }
-      const float *ab = p.x + ci0, *bb = p.w + kbase;
+      const uint32_t wk = TCONV ? (uint32_t)(((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0) : (uint32_t)kbase;
+      const float *ab = p.x + ci0, *bb = p.w + wk;
       const uint32_t dst = wdst + (uint32_t)stage * STAGE_B;
+      if (!TCONV || tap_all_in) {
 #pragma unroll
-      for (int j = 0; j < GA; ++j) glds16(ab, g_avo[j], dst + j * 4096);
+        for (int j = 0; j < GA; ++j) glds16(ab, g_avo[j], dst + j * 4096);
+      } else {
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+          if (g_in[j]) glds16(ab, g_avo[j], dst + j * 4096);
+          else *reinterpret_cast<float4 *>(ring + stage * STAGE_B + (32 * j + 8 * wave) * ROWB + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < GB; ++j) glds16(bb, g_bvo[j], dst + BM * ROWB + j * 4096);
     };
@@ -465,8 +495,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       mfma_step(I1{}, I0{});
       AIVC_SB();
       if (kt + 1 < nkt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of tile kt + 1 have landed ...
-        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; everybody is done reading this stage
+        // this wave's DMAs (and zero fills) of tile kt + 1 have landed ...
+        if (TCONV) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... and everybody else's; everybody is done reading this stage
       }
       AIVC_SB();
       mfma_step(I1{}, I1{});
@@ -481,7 +513,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       AIVC_SB();
     };
     issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nkt > 1) issue_tile(1, 1);
     read_oct(I0{}, I0{}, I0{});
@@ -1037,20 +1069,30 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
 #endif
   size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
   if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per instantiation
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("conv_mfma lds attribute");
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
 // LDS-DMA K loop: conv with c_in % 32 == 0 on the tiles it is instantiated for; per-lane BYTE offsets are 32 bits
 static bool use_glds(const aivc_conv_params &p) {
-  static const int off = getenv("AIVC_NO_GLDS") ? 1 : 0;  // tuning aid: the register-staged loop everywhere
-  if (off || p.mode != AIVC_MODE_CONV || p.c_in % BK != 0) return false;
+  static const int off = getenv("AIVC_NO_GLDS") ? atoi(getenv("AIVC_NO_GLDS")) : 0;  // tuning aid: 1 = the register-staged loop everywhere, 2 = for transposed conv
+  if (off == 1 || (off == 2 && p.mode == AIVC_MODE_TCONV) || (p.mode != AIVC_MODE_CONV && p.mode != AIVC_MODE_TCONV) || p.c_in % BK != 0) return false;
   return (uint64_t)p.n * p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFFFull && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 4ull < 0xFFFFFFFFull;
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
 static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
-  if constexpr (MODE == AIVC_MODE_CONV && WM == 2 && WN == 2 && TM == 2 && (TN == 2 || TN == 1)) {
+  // every tile of the menu except 256x128 (96 KB of ring: one workgroup per CU)
+  if constexpr ((MODE == AIVC_MODE_CONV || MODE == AIVC_MODE_TCONV) && 32 * WM * TM + 32 * WN * TN <= 320) {
     if (use_glds(p)) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true, false, true>(p, s);
   }
   if (p.c_in % BK == 0) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true>(p, s);
