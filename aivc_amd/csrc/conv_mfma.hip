@@ -405,10 +405,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + chunk_b;
     }
     const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
-    auto issue_tile = [&](int kt, int stage) {
-      const int kbase = kt * BK;
-      int ty, tx, ci0;
-      tap_of(kbase, ty, tx, ci0);  // wave-uniform
+    // tiles are issued in K order: the (tap, channel offset) of the next one is kept as running scalars
+    int ty = 0, tx = 0, ci0 = 0;
+    const float *wrun = p.w;  // conv: weight row offset of the next tile
+    auto issue_tile = [&](int stage) {
       if (ci0 == 0) {              // new kernel tap: the per-lane pixel offsets change
         const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
         bool all_in = true;
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
         }
         if (TCONV) tap_all_in = __builtin_amdgcn_ballot_w64(all_in) == ~0ull;
       }
-      const uint32_t wk = TCONV ? (uint32_t)(((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0) : (uint32_t)kbase;
-      const float *ab = p.x + ci0, *bb = p.w + wk;
+      const float *ab = p.x + ci0;
+      const float *bb = TCONV ? p.w + (((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0) : wrun;
       const uint32_t dst = wdst + (uint32_t)stage * STAGE_B;
       if (!TCONV || tap_all_in) {
 #pragma unroll
@@ -440,6 +440,15 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       }
 #pragma unroll
       for (int j = 0; j < GB; ++j) glds16(bb, g_bvo[j], dst + BM * ROWB + j * 4096);
+      wrun += BK;
+      ci0 += BK;
+      if (ci0 == Cin) {
+        ci0 = 0;
+        if (++tx == nkx) {
+          tx = 0;
+          ++ty;
+        }
+      }
     };
     // fragment reads: lane reads row (lane & 31) of its 32-row blocks, data chunk 2 o + (lane >> 5)
     const int sw = (lane & 7) ^ ((lane >> 3) & 3);
@@ -477,8 +486,9 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     using I3 = integral_constant<int, 3>;
 #define AIVC_SB() __builtin_amdgcn_sched_barrier(0)
     auto oct_mfmas = [&](auto SET) { mfma_step(SET, I0{}); mfma_step(SET, I1{}); mfma_step(SET, I2{}); mfma_step(SET, I3{}); };
-    auto body = [&](auto STAGE, int kt) {
+    auto body = [&](auto STAGE, auto CHECK, int kt) {  // CHECK false: the caller guarantees kt + 2 < nkt
       constexpr int stage = decltype(STAGE)::value;
+      constexpr bool chk = decltype(CHECK)::value;
       using NEXT = integral_constant<int, 1 - stage>;
       read_oct(I1{}, STAGE, I1{});
       AIVC_SB();
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       AIVC_SB();
       mfma_step(I1{}, I0{});
       AIVC_SB();
-      if (kt + 1 < nkt) {
+      if (!chk || kt + 1 < nkt) {
         // this wave's DMAs (and zero fills) of tile kt + 1 have landed ...
         if (TCONV) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -503,24 +513,31 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       AIVC_SB();
       mfma_step(I1{}, I1{});
       AIVC_SB();
-      if (kt + 1 < nkt) read_oct(I0{}, NEXT{}, I0{});
+      if (!chk || kt + 1 < nkt) read_oct(I0{}, NEXT{}, I0{});
       AIVC_SB();
       mfma_step(I1{}, I2{});
       AIVC_SB();
-      if (kt + 2 < nkt) issue_tile(kt + 2, stage);
+      if (!chk || kt + 2 < nkt) issue_tile(stage);
       AIVC_SB();
       mfma_step(I1{}, I3{});
       AIVC_SB();
     };
-    issue_tile(0, 0);
+    issue_tile(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nkt > 1) issue_tile(1, 1);
+    if (nkt > 1) issue_tile(1);
     read_oct(I0{}, I0{}, I0{});
-    for (int kt = 0; kt < nkt; kt += 2) {
+    using std::false_type;
+    using std::true_type;
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 2) {  // both tiles of the pair have two successors: no end-of-reduction tests
       if (kt == 2) { DBG_T(2); }
-      body(I0{}, kt);
-      if (kt + 1 < nkt) body(I1{}, kt + 1);
+      body(I0{}, false_type{}, kt);
+      body(I1{}, false_type{}, kt + 1);
+    }
+    for (; kt < nkt; kt += 2) {
+      body(I0{}, true_type{}, kt);
+      if (kt + 1 < nkt) body(I1{}, true_type{}, kt + 1);
     }
 #undef AIVC_SB
     __syncthreads();  // the ring is reused (padded layout) by the fused phases below
