@@ -417,12 +417,12 @@ def main():
             all_fl = sum(d[1] for d in mf.values())
             all_sec = sum(d[2] for d in mf.values())
             traffic, traffic_note, counters = None, None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant.json')  # counter passes on this shape at batch 16 (tools/pmc_conv.sh)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
                     traffic = pj.get('traffic_bytes_per_launch')
-                    traffic_note = pj.get('note')
+                    traffic_note = 'counter passes at batch %s (the batch of this kernel\'s launches in the bench is 16 / 8 / 4); ' % pj.get('probe_batch') + pj.get('note')
                     counters = pj.get('sq_counters')
             roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
                         'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
