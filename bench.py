@@ -252,6 +252,12 @@ def main():
     use_dist = world > 1 or bool(os.environ.get('AIVC_FORCE_DIST'))  # (the env var exercises the RCCL path on 1 GPU)
     backend = os.environ.get('AIVC_DIST_BACKEND', 'nccl')
     if use_dist:
+        if 'RANK' not in os.environ:  # AIVC_FORCE_DIST=1 python bench.py: a one-rank job of its own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                                  MASTER_PORT=str(sk.getsockname()[1]))
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
