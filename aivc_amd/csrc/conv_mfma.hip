@@ -357,9 +357,9 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     // ---- LDS-DMA K loop (round 3) -----------------------------------------------------------------------------
     // Operand tiles go global -> LDS by global_load_lds_dwordx4: no staging registers, no ds_write pass, no per-K-tile
     // address arithmetic on the vector unit (the K-tile's channel offset sits in the scalar base, the per-lane pixel
-    // offset changes only with the kernel tap).  What that buys on this part, where every issued instruction costs
-    // the fp32 matrix pipe ~4.4 cycles and the clock is power-limited (tools/glds_probe.hip: 2.14 GHz with register
-    // staging, 2.23 GHz with LDS-DMA at the same tile): fewer instructions per MFMA and a higher clock.
+    // offset changes only with the kernel tap).  What that buys on this part: the sustained
+    // fp32 MFMA rate is capped near 135 TFLOP/s by a limiter that trades clock against pipe use, so the way up is
+    // less data movement per MFMA -- 0.27 instead of 0.39 LDS instructions per MFMA, no VGPR round trip.
     //   LDS image   two stages of (BM + BN) rows x 128 bytes, UNPADDED (a DMA writes 64 x 16 contiguous bytes: 8
     //               rows), XOR-swizzled instead: the 16-byte slot s of row R holds data chunk s ^ swz(R),
     //               swz(R) = (R & 7) ^ ((R >> 3) & 3) -- applied on the SOURCE address of the DMA and on the
@@ -1225,7 +1225,33 @@ bool conv2d_mfma_supported(const aivc_conv_params &p) {
   return true;
 }
 
+// byte size of the input tensor / of the weights as the LDS-DMA loader addresses them (32-bit byte offsets)
+static bool glds_sizes_ok(const aivc_conv_params &p) {
+  return (uint64_t)p.n * p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFFFull;
+}
+
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
+  // a batch whose input exceeds the 4 GB the LDS-DMA loader can address goes out as several launches over
+  // sub-batches (images are independent; same kernels, same results)
+  if ((p.mode == AIVC_MODE_CONV || p.mode == AIVC_MODE_TCONV) && p.c_in % BK == 0 && p.n > 1 && !glds_sizes_ok(p) &&
+      !getenv("AIVC_NO_GLDS")) {
+    const uint64_t per_image = (uint64_t)p.h_in * p.w_in * p.c_in * 4ull;
+    int chunk = (int)(0xFFFFFFF0ull / per_image);
+    if (chunk >= 1) {
+      const int c_y = p.tail_c_out ? p.tail_c_out : p.c_out;
+      for (int n0 = 0; n0 < p.n; n0 += chunk) {
+        aivc_conv_params q = p;
+        q.n = p.n - n0 < chunk ? p.n - n0 : chunk;
+        const size_t in_off = (size_t)n0 * p.h_in * p.w_in * p.c_in, out_off = (size_t)n0 * p.h_out * p.w_out * c_y;
+        q.x = p.x + in_off;
+        q.y = p.y + out_off;
+        if (p.res) q.res = p.res + out_off;
+        if (p.mul) q.mul = p.mul + out_off;
+        if (const int rc = conv2d_mfma(q, s)) return rc;
+      }
+      return AIVC_OK;
+    }
+  }
   if (p.tail_c_out) {
     if (!conv2d_mfma_tail_supported(p)) return AIVC_ERR_UNSUPPORTED;
     if (use_glds(p)) return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true, true>(p, s);

@@ -87,3 +87,25 @@ def test_range_coder_round_trip_4k_latent(cuda):
     want = (q.permute(3, 0, 1, 2).reshape(-1).to(torch.int32) + 256).to(torch.int16)
     assert (q.abs() > 40).any(), 'the sweep must leave the 64-entry window'
     assert torch.equal(dec.view(torch.int16).reshape(-1), want)
+
+
+def test_batch_beyond_4gb_goes_out_as_sub_batches(cuda):
+    """the LDS-DMA loader addresses its input with 32-bit BYTE offsets: a batch of more than 4 GB (34 half-resolution
+    64-channel maps of a 1080p frame = 4.5 GB) is split into sub-batch launches inside aivc_conv2d -- same bits as the
+    caller splitting it, fused GDN and the transposed conv included"""
+    from aivc_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(21)
+    x = torch.randn((34, 540, 960, 64), generator=g).to(cuda)
+    w = (torch.randn((128, 5, 5, 64), generator=g) / 40.0).to(cuda)
+    b = torch.randn(128, generator=g).to(cuda)
+    beta = (torch.rand(128, generator=g) + 0.5).to(cuda)
+    gamma = (torch.rand((128, 128), generator=g) * 0.01).to(cuda)
+    assert x.numel() * 4 > 2 ** 32
+    full = ops.conv2d(x, w, b, stride=2, pad=2, gdn=(beta, gamma, False))
+    for lo, hi in ((0, 17), (17, 34)):
+        assert torch.equal(full[lo:hi], ops.conv2d(x[lo:hi].contiguous(), w, b, stride=2, pad=2, gdn=(beta, gamma, False)))
+    del full
+    wt = (torch.randn((32, 3, 3, 64), generator=g) / 24.0).to(cuda)
+    bt = torch.randn(32, generator=g).to(cuda)
+    full = ops.conv2d(x, wt, bt, mode=abi.MODE_TCONV, stride=2, act1=abi.ACT_LEAKY)
+    assert torch.equal(full[30:34], ops.conv2d(x[30:34].contiguous(), wt, bt, mode=abi.MODE_TCONV, stride=2, act1=abi.ACT_LEAKY))
