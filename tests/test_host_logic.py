@@ -139,3 +139,44 @@ def test_md5_debug_digest_is_the_reference_procedure(tmp_path):
     np.savetxt(path, x_nchw.flatten())
     want = hashlib.md5(open(path, 'rb').read()).hexdigest().encode()
     assert latent_md5(q) == want and len(want) == 32
+
+
+def test_debug_digest_kinds(tmp_path, capsys):
+    """flag_bitstream_debug: a bare digest is the md5 of the PNG file (the reference's), 'raw:<md5>' that of the 8-bit
+    plane; the decoder compares like with like (src/real_life/decode.py:304-326)"""
+    import hashlib
+    import numpy as np
+    import torch
+    from aivc_amd.real_life import decode as dec
+    rng = np.random.default_rng(1)
+    frames = [{k: torch.from_numpy(rng.integers(0, 256, (1, 6, 8) if k == 'y' else (1, 3, 4), dtype=np.uint8)) for k in 'yuv'}]
+    d = str(tmp_path / 'dbg')
+    dec.write_debug_md5(frames, 5, d)
+    assert dec.check_debug_md5(frames, 5, d) == 0
+    raw = hashlib.md5(frames[0]['y'].numpy().tobytes()).hexdigest()
+    assert dec.plane_md5(frames[0]['y'], 'raw') == raw
+    with open(tmp_path / 'dbg' / '5_y.md5', 'w') as f:  # an encoder without Pillow wrote this one
+        f.write('raw:' + raw)
+    assert dec.check_debug_md5(frames, 5, d) == 0
+    with open(tmp_path / 'dbg' / '5_u.md5', 'w') as f:
+        f.write('raw:' + raw)  # wrong plane
+    assert dec.check_debug_md5(frames, 5, d) == 1
+    assert 'Incorrect reconstruction' in capsys.readouterr().out
+
+
+def test_clip_shard_is_built_once():
+    """clip_shard() keeps one ClipShard per (units, world, device): constructing one allocates communicators"""
+    import torch
+    from aivc_amd import parallel
+    a = parallel.clip_shard(4, torch.device('cpu'))
+    assert parallel.clip_shard(4, torch.device('cpu')) is a and parallel.clip_shard(3, torch.device('cpu')) is not a
+    assert (a.G, a.R, a.units) == (1, 1, [0, 1, 2, 3])
+
+
+def test_bench_cli_parses():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and '--gpus' in (out.stdout + out.stderr) and '--active-y' in (out.stdout + out.stderr)
