@@ -1153,6 +1153,16 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   // 128x64 (id 6: 126 registers, four waves per SIMD) is ahead where the epilogue weighs most against a short or
   // loader-heavy reduction: the image layers (c_in of 4 / 8 / 12), 1x1 and stride-2 convs (r02: 4080 vs 4232 us,
   // 114 vs 119, 548 vs 582); transposed convs and the 3x3 stay on 256x64 / 64x64
+  // Round 3, LDS-DMA loop (c_in % 32 == 0; tools/bench_conv.py with AIVC_FORCE_TILE, same box): 64x128 (three
+  // workgroups per CU: 48 KB of ring, <= 172 registers) beats 128x128 (two) wherever BN = 128 fits -- 5x5 s2 64->128
+  // + GDN 135.3 -> 137.8, 3x3 128->128 138.4 -> 140.3 (+ GDN 131.9 -> 133.5), transposed 5x5 128->128 122.6 -> 132.9
+  // (+ GDN 114.6 -> 127.4), transposed 3x3 115.0 -> 118.5 TFLOP/s; for c_out = 64 the transposed 5x5 + GDN runs
+  // 121.5 on 256x64, 125.1 on 128x64, 125.6 on 64x64.  AIVC_TILE_RULES_R2 restores the round-2 rules below.
+  static const bool r2_rules = getenv("AIVC_TILE_RULES_R2") != nullptr;
+  if (!r2_rules && p.c_in % BK == 0 && (p.mode == AIVC_MODE_CONV || t)) {
+    if (co % 128 == 0) return 5;
+    if (co <= 64 && t) return 1;
+  }
   if (co <= 64 && !t && M >= 65536 && (p.c_in % BK != 0 || p.ksize == 1 || p.stride == 2)) return 6;
   if (co <= 64) return (M >= 250000 && kred >= 96 && p.c_in % BK == 0) ? 2 : 1;
   if (p.gdn) return (t && p.ksize == 3) ? 5 : 0;  // BN must equal c_out = 128
@@ -1254,7 +1264,11 @@ int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
   }
   if (p.tail_c_out) {
     if (!conv2d_mfma_tail_supported(p)) return AIVC_ERR_UNSUPPORTED;
-    if (use_glds(p)) return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true, true>(p, s);
+    if (use_glds(p)) {
+      static const int tail_tile = getenv("AIVC_TAIL_TILE") ? atoi(getenv("AIVC_TAIL_TILE")) : 6;  // tuning aid: 1 = 64x64
+      if (tail_tile == 1) return launch_cfg2<AIVC_MODE_CONV, 2, 2, 1, 1, false, true, true, true>(p, s);
+      return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true, true>(p, s);
+    }
     return launch_cfg2<AIVC_MODE_CONV, 2, 2, 2, 1, false, true, true>(p, s);
   }
   switch (p.mode) {
