@@ -428,7 +428,7 @@ def main():
                 pj = json.load(open(pmc))
                 if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
                     traffic = pj.get('traffic_bytes_per_launch')
-                    traffic_note = 'counter passes at batch %s (the batch of this kernel\'s launches in the bench is 16 / 8 / 4); ' % pj.get('probe_batch') + pj.get('note')
+                    traffic_note = 'counter passes at batch %s (the bench launches this kernel at 32 -- its 64-frame level in two halves -- 16, 8 and 4 frames); ' % pj.get('probe_batch') + pj.get('note')
                     counters = pj.get('sq_counters')
             roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
                         'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
