@@ -60,6 +60,14 @@ CONV_CASES = [
     (abi.MODE_TCONV, 5, 2, 0, 48, 6, 8, 33, 0, abi.ACT_LEAKY, True, True),
     (abi.MODE_TCONV, 3, 2, 0, 96, 3, 1, 1, 0, 0, False, False),
     (abi.MODE_TCONV, 5, 2, 0, 64, 6, 6, 10, abi.ACT_SIGMOID, 0, False, False),  # falls back to the VALU kernel
+    # LDS-DMA K loop corner cases: a reduction of ONE K-tile (1x1, c_in 32), of an odd number (3x3 x 32 = 9), two
+    # tiles; transposed with image-border zero fill on every tile; c_out beyond the tile width; rows beyond M
+    (abi.MODE_CONV, 1, 1, 0, 32, 64, 9, 13, 0, 0, False, False),
+    (abi.MODE_CONV, 3, 1, 1, 32, 32, 11, 7, abi.ACT_LEAKY, 0, False, True),
+    (abi.MODE_CONV, 1, 2, 0, 64, 128, 5, 3, 0, abi.ACT_RELU, False, True),
+    (abi.MODE_TCONV, 3, 2, 0, 32, 64, 7, 9, 0, 0, False, False),
+    (abi.MODE_TCONV, 5, 2, 0, 64, 128, 1, 3, abi.ACT_LEAKY, 0, False, False),
+    (abi.MODE_CONV, 5, 2, 2, 96, 160, 13, 9, 0, 0, False, False),
 ]
 
 
