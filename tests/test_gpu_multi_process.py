@@ -83,3 +83,71 @@ def test_single_rank_clip_shard_is_the_plain_path(cuda):
         ref_blobs, _, ref_dd = fc.encode_units(units, 'LDP_2')
         recs = parallel.decode_clip(fc, blobs, dd, dev)
     assert blobs == ref_blobs and dd == ref_dd and sorted(recs) == [0, 1]
+
+
+def test_exchange_frames_device_side_plumbing(cuda, monkeypatch):
+    """ClipShard.exchange_frames with the tensors an RCCL run hands it (uint8 CUDA planes, CUDA send / receive buffers,
+    asynchronous collective): the box has one GPU and RCCL refuses two ranks per device, so the collective itself is
+    replaced by a stand-in that delivers what rank 1 of a two-rank group would send -- packing, slot order and the
+    views handed back are the product's."""
+    import torch.distributed as dist
+    from aivc_amd import parallel
+    h, w = 34, 50
+    hc, wc = 17, 25
+    g = torch.Generator(device='cpu').manual_seed(5)
+
+    def frame():
+        return {'y': torch.randint(0, 256, (1, h, w), generator=g, dtype=torch.uint8).to(cuda),
+                'u': torch.randint(0, 256, (1, hc, wc), generator=g, dtype=torch.uint8).to(cuda),
+                'v': torch.randint(0, 256, (1, hc, wc), generator=g, dtype=torch.uint8).to(cuda)}
+    items = [(0, 'frame_%d' % i) for i in range(5)]  # 5 frames over 2 ranks: rank 0 codes 0, 2, 4; rank 1 codes 1, 3
+    frames = [frame() for _ in items]
+    sh = parallel.ClipShard.__new__(parallel.ClipShard)
+    sh.rank, sh.world, sh.G, sh.R, sh.local, sh.pg, sh.device, sh._bufs = 0, 2, 1, 2, 0, None, cuda, {}
+    other = torch.cat([torch.cat([frames[j][k].reshape(-1) for k in 'yuv']) for j in (1, 3)])
+
+    class Work:
+        def wait(self):
+            return True
+
+    def fake_all_gather(recv, send, group=None, async_op=False):
+        assert recv.is_cuda and send.is_cuda and recv.dtype == torch.uint8 and async_op
+        per = send.numel()
+        recv[:per] = send
+        recv[per:per + other.numel()] = other
+        return Work()
+    monkeypatch.setattr(dist, 'all_gather_into_tensor', fake_all_gather)
+    monkeypatch.setattr(dist, 'get_backend', lambda group=None: 'nccl')
+    got = sh.exchange_frames(items, [frames[j] for j in (0, 2, 4)], h, w, cuda)
+    assert len(got) == 5
+    for a, b in zip(got, frames):
+        assert all(torch.equal(a[k], b[k]) and a[k].shape == b[k].shape for k in 'yuv')
+    # the persistent send buffer is reused by the next level
+    got2 = sh.exchange_frames(items, [frames[j] for j in (0, 2, 4)], h, w, cuda)
+    assert len(sh._bufs) == 1 and all(torch.equal(a[k], b[k]) for a, b in zip(got2, frames) for k in 'yuv')
+
+
+def test_gather_bytes_device_side_plumbing(cuda, monkeypatch):
+    """gather_bytes_all as an RCCL run drives it (int64 lengths and uint8 payload as CUDA tensors), the second rank's
+    contribution supplied by a stand-in collective"""
+    import torch.distributed as dist
+    from aivc_amd import parallel
+    keys = [0, 1, 2, 3, 'dd']
+    mine = {0: b'unit zero', 2: b'\x00\x01\x02' * 50, 'dd': b'D' * 24}
+    theirs = {1: b'', 3: b'unit three!'}
+    calls = []
+
+    def fake_all_gather(recv, send, group=None, async_op=False):
+        assert recv.is_cuda and send.is_cuda
+        n = send.numel()
+        recv[:n] = send
+        if send.dtype == torch.int64:
+            recv[n:] = torch.tensor([len(theirs[k]) if k in theirs else -1 for k in keys], dtype=torch.int64, device=send.device)
+        else:
+            pay = b''.join(theirs[k] for k in keys if k in theirs)
+            recv[n:n + len(pay)] = torch.frombuffer(bytearray(pay), dtype=torch.uint8).to(send.device)
+        calls.append(send.dtype)
+    monkeypatch.setattr(dist, 'all_gather_into_tensor', fake_all_gather)
+    monkeypatch.setattr(dist, 'get_backend', lambda group=None: 'nccl')
+    out = parallel.gather_bytes_all(mine, keys, None, 2, cuda)
+    assert out == dict(mine, **theirs) and calls == [torch.int64, torch.uint8]
