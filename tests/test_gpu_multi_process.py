@@ -150,4 +150,6 @@ def test_gather_bytes_device_side_plumbing(cuda, monkeypatch):
     monkeypatch.setattr(dist, 'all_gather_into_tensor', fake_all_gather)
     monkeypatch.setattr(dist, 'get_backend', lambda group=None: 'nccl')
     out = parallel.gather_bytes_all(mine, keys, None, 2, cuda)
-    assert out == dict(mine, **theirs) and calls == [torch.int64, torch.uint8]
+    want = dict(mine)
+    want.update(theirs)
+    assert out == want and calls == [torch.int64, torch.uint8]
