@@ -370,7 +370,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     //               fragments in registers).  Accumulation order unchanged: octets ascending, AIVC_K_ORDER inside.
     //   transposed  out-of-image taps (zero fill): such lanes take no part in the DMA and write 16 zero bytes to their
     //   conv        slot instead; tiles away from the image border never see the branch (wave-uniform test per tap).
-    static_assert(FASTK && !GDN, "LDS-DMA loop: conv / transposed conv with c_in % 32 == 0");
+    //   generic K   (c_in % 32 != 0: the image layers, c_in of 4 / 8 / 12; conv only) a 16-byte chunk is one (tap, 4 input
+    //               channels) quad: every lane decodes the quad of its chunk once per K-tile -- the same for all of its
+    //               rows -- and clamps per row; the quads beyond K of the last tile write zeros instead of loading.
+    static_assert(!GDN && (FASTK || MODE == AIVC_MODE_CONV), "LDS-DMA loop: conv / transposed conv (c_in % 32 == 0), conv (any c_in % 4 == 0)");
     constexpr int ROWB = BK * 4, STAGE_B = (BM + BN) * ROWB, GA = BM / 32, GB = BN / 32;
     char *ring = reinterpret_cast<char *>(smem);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
@@ -402,13 +405,35 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     for (int j = 0; j < GB; ++j) {
       const int co = n0 + 32 * j + 8 * wave + l3;
       const int coc = co < Cout ? co : Cout - 1;  // rows beyond c_out are never stored
-      g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + chunk_b;
+      g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + (FASTK ? chunk_b : 0u);
     }
     const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
     // tiles are issued in K order: the (tap, channel offset) of the next one is kept as running scalars
     int ty = 0, tx = 0, ci0 = 0;
     const float *wrun = p.w;  // conv: weight row offset of the next tile
-    auto issue_tile = [&](int stage) {
+    int kt_next = 0;           // generic K: index of the next tile to issue
+    auto issue_tile_generic = [&](int stage) {
+      const int kk = kt_next * BK + (int)(chunk_b >> 2);  // first reduction index of this lane's quad
+      const bool qok = kk < K;                            // beyond K (last tile only): zeros
+      int qty, qtx, qci;
+      tap_of(qok ? kk : 0, qty, qtx, qci);
+      const bool tail = (kt_next + 1) * BK > K;           // wave-uniform
+      const uint32_t dst = wdst + (uint32_t)stage * STAGE_B;
+#pragma unroll
+      for (int j = 0; j < GA; ++j) {
+        const int iy = max(min(g_by[j] + qty, H - 1), 0), ix = max(min(g_bx[j] + qtx, W - 1), 0);
+        const uint32_t off = ((g_nb[j] + (uint32_t)(iy * W + ix)) * (uint32_t)Cin + (uint32_t)qci) * 4u;
+        if (!tail || qok) glds16(p.x, off, dst + j * 4096);
+        else *reinterpret_cast<float4 *>(ring + stage * STAGE_B + (32 * j + 8 * wave) * ROWB + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        if (!tail || qok) glds16(p.w, g_bvo[j] + (uint32_t)kk * 4u, dst + BM * ROWB + j * 4096);
+        else *reinterpret_cast<float4 *>(ring + stage * STAGE_B + (BM + 32 * j + 8 * wave) * ROWB + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      ++kt_next;
+    };
+    auto issue_tile_fast = [&](int stage) {
       if (ci0 == 0) {              // new kernel tap: the per-lane pixel offsets change
         const int dyt = (pyc + tpad - (ky0 + 2 * ty)) >> 1, dxt = (pxc + tpad - (kx0 + 2 * tx)) >> 1;
         bool all_in = true;
@@ -450,6 +475,10 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
         }
       }
     };
+    auto issue_tile = [&](int stage) {
+      if constexpr (FASTK) issue_tile_fast(stage);
+      else issue_tile_generic(stage);
+    };
     // fragment reads: lane reads row (lane & 31) of its 32-row blocks, data chunk 2 o + (lane >> 5)
     const int sw = (lane & 7) ^ ((lane >> 3) & 3);
     const char *a_rd[OCT], *b_rd[OCT];
@@ -469,6 +498,9 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     };
     auto mfma_step = [&](auto SET, auto S) {
       constexpr int set = decltype(SET)::value, st = decltype(S)::value;
+      if constexpr (!FASTK && st == 3) {
+        if (skip3) return;  // AIVC_CONV_SPARSE4: k % 4 == 3 multiplies the zero pad channel of an image (exact no-op)
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const float av = st == 0 ? fa[set][i].x : (st == 1 ? fa[set][i].y : (st == 2 ? fa[set][i].z : fa[set][i].w));
@@ -506,7 +538,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
       AIVC_SB();
       if (!chk || kt + 1 < nkt) {
         // this wave's DMAs (and zero fills) of tile kt + 1 have landed ...
-        if (TCONV) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (TCONV || !FASTK) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... and everybody else's; everybody is done reading this stage
       }
@@ -1102,7 +1134,8 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
 // LDS-DMA K loop: conv with c_in % 32 == 0 on the tiles it is instantiated for; per-lane BYTE offsets are 32 bits
 static bool use_glds(const aivc_conv_params &p) {
   static const int off = getenv("AIVC_NO_GLDS") ? atoi(getenv("AIVC_NO_GLDS")) : 0;  // tuning aid: 1 = the register-staged loop everywhere, 2 = for transposed conv
-  if (off == 1 || (off == 2 && p.mode == AIVC_MODE_TCONV) || (p.mode != AIVC_MODE_CONV && p.mode != AIVC_MODE_TCONV) || p.c_in % BK != 0) return false;
+  if (off == 1 || (off == 2 && p.mode == AIVC_MODE_TCONV) || (p.mode != AIVC_MODE_CONV && p.mode != AIVC_MODE_TCONV)) return false;
+  if (p.c_in % BK != 0 && (p.mode != AIVC_MODE_CONV || off == 3)) return false;  // generic K: conv only (3 = tuning aid: off)
   return (uint64_t)p.n * p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFFFull && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 4ull < 0xFFFFFFFFull;
 }
 
@@ -1110,7 +1143,10 @@ template <int MODE, int WM, int WN, int TM, int TN, bool FUSE>
 static int launch_cfg(const aivc_conv_params &p, hipStream_t s) {
   // every tile of the menu except 256x128 (96 KB of ring: one workgroup per CU)
   if constexpr ((MODE == AIVC_MODE_CONV || MODE == AIVC_MODE_TCONV) && 32 * WM * TM + 32 * WN * TN <= 320) {
-    if (use_glds(p)) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true, false, true>(p, s);
+    if (use_glds(p)) {
+      if (p.c_in % BK == 0) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true, false, true>(p, s);
+      if constexpr (MODE == AIVC_MODE_CONV && !(WM == 4 && TM == 2)) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, false, false, true>(p, s);
+    }
   }
   if (p.c_in % BK == 0) return launch_cfg2<MODE, WM, WN, TM, TN, FUSE, true>(p, s);
   if constexpr (WM == 4 && TM == 2) return AIVC_ERR_UNSUPPORTED;  // pick_tile never sends a generic reduction here
@@ -1243,7 +1279,7 @@ static bool glds_sizes_ok(const aivc_conv_params &p) {
 int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
   // a batch whose input exceeds the 4 GB the LDS-DMA loader can address goes out as several launches over
   // sub-batches (images are independent; same kernels, same results)
-  if ((p.mode == AIVC_MODE_CONV || p.mode == AIVC_MODE_TCONV) && p.c_in % BK == 0 && p.n > 1 && !glds_sizes_ok(p) &&
+  if ((p.mode == AIVC_MODE_CONV || (p.mode == AIVC_MODE_TCONV && p.c_in % BK == 0)) && p.n > 1 && !glds_sizes_ok(p) &&
       !getenv("AIVC_NO_GLDS")) {
     const uint64_t per_image = (uint64_t)p.h_in * p.w_in * p.c_in * 4ull;
     int chunk = (int)(0xFFFFFFF0ull / per_image);
