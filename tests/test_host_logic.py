@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     p = abi.ConvParams(abi.MODE_CONV, 3, 2, 1, 1, 9, 9, 4, 4, 5, 4, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None)
     assert fns['aivc_conv2d'](ctypes.byref(p), None) == -1  # wrong output size
     assert fns['aivc_conv2d_variant'](ctypes.byref(abi.ConvParams(
-        abi.MODE_CONV, 3, 1, 1, 1, 270, 480, 128, 270, 480, 128, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None))) == 100  # 128x128
+        abi.MODE_CONV, 3, 1, 1, 1, 270, 480, 128, 270, 480, 128, 0, 0, 0, 0, 0, 1, 1, None, None, None, 1, None, None))) == 105  # 64x128 (round-3 tile rules)
 
 
 def test_product_path_refuses_cpu_tensors():
