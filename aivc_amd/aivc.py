@@ -41,13 +41,18 @@ def main(argv=None):
     a = p.parse_args(argv)
     gop = gop_name(a.coding_config, a.gop_size, a.intra_period)
     common = ['--model', a.model] + (['--cpu'] if a.cpu else [])
-    print(('*' * 80).center(120))
-    print('Starting encoding'.center(120))
+    import os
+    banner = print if int(os.environ.get('RANK', '0')) == 0 else (lambda *x: None)  # one voice in a multi-rank job
+    banner(('*' * 80).center(120))
+    banner('Starting encoding'.center(120))
     enc_cli.main(['-i', a.i, '--gop', gop, '--start_frame', str(a.start_frame), '--end_frame', str(a.end_frame),
                   '-o', a.bitstream_out] + common)
-    print(('*' * 80).center(120))
-    print('Starting decoding'.center(120))
+    banner(('*' * 80).center(120))
+    banner('Starting decoding'.center(120))
     dec_cli.main(['-i', a.bitstream_out, '-o', a.o] + common)
+    from aivc_amd import parallel
+    if parallel.rank_world()[0] != 0:  # multi-rank job: rank 0 evaluates
+        return
     print(('*' * 80).center(120))
     print('Starting evaluation'.center(120))
     eval_cli.main(['--raw', a.i, '--compressed', a.o, '--bitstream', a.bitstream_out, '--start_frame', str(a.start_frame)])

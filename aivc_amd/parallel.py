@@ -49,8 +49,9 @@ def gather_gops(local_gops, dst=0, device=None):
     return [allb[u] for u in keys]
 
 
-def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, idx_rate=0.):
-    """Every rank passes the same `frames`; returns the full bitstream on rank 0 (None elsewhere)."""
+def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, idx_rate=0., return_enc=False):
+    """Every rank passes the same `frames`; returns the full bitstream on rank 0 (None elsewhere); with return_enc also
+    this rank's encode_video record (its units' reconstructions, None for the others')."""
     rank, world = rank_world()
     enc = frame_codec.encode_video(frames, gop_name, idx_starting_frame, idx_rate=idx_rate,
                                    unit_filter=lambda u: unit_owner(u, world) == rank)
@@ -66,9 +67,9 @@ def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, id
         v = [int(x) for x in t.cpu()]
         data_dim = {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
     if gops is None:
-        return None
-    enc = dict(enc, gops=gops, data_dim=data_dim)
-    return frame_codec.assemble_video(enc)
+        return (None, enc) if return_enc else None
+    blob = frame_codec.assemble_video(dict(enc, gops=gops, data_dim=data_dim))
+    return (blob, enc) if return_enc else blob
 
 
 def decode_video_sharded(frame_codec, blob, device=None):

@@ -99,10 +99,20 @@ def decode_one_video(param):
         blob = f.read()
     print_log_msg('INFO', 'Start decoding', '', '')
     t0 = time.time()
+    from .. import parallel
+    from . import cat_binary_files as container
+    rank, world = parallel.rank_world()
     with torch.no_grad():
-        frames, data_dim, first, last = FrameCodec(decoder.full_net).decode_video(blob, dev)
+        if world > 1:  # one process per GPU: every rank decodes its intra-period units, rank 0 collects the planes
+            _, first, last, _ = container.unpack_video(blob)
+            frames = parallel.decode_video_sharded(FrameCodec(decoder.full_net), blob, dev)
+        else:
+            frames, data_dim, first, last = FrameCodec(decoder.full_net).decode_video(blob, dev)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if rank != 0:
+        dist_barrier_after_write(world)
+        return None
     n = last - first + 1
     print_log_msg('INFO', 'Decoding done', '', '')
     print_log_msg('RESULT', 'Number of frames', '[frame]', int(n))
@@ -110,9 +120,17 @@ def decode_one_video(param):
     print_log_msg('RESULT', 'Decoding FPS', '[frame/s]', '%.1f' % (n / dt))
     if out_file:
         write_yuv(frames, out_file)
+    dist_barrier_after_write(world)
     if get_value('flag_bitstream_debug', param, default):
         check_debug_md5(frames, first, debug_dir(path))
     return frames
+
+
+def dist_barrier_after_write(world):
+    """multi-rank CLI: nobody goes on (to evaluate the output file) before rank 0 has written it"""
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def debug_dir(bitstream_path):

@@ -55,24 +55,50 @@ def encode(param):
     print_log_msg('INFO', 'Start encoding', '', '')
     t0 = time.time()
     fc = FrameCodec(model)
+    from .. import parallel
+    rank, world = parallel.rank_world()
     with torch.no_grad():
-        enc = fc.encode_video(frames, gop_name, idx_starting_frame=first, idx_end_frame=last,
-                              idx_rate=get_value('idx_rate', param, default))
-        blob = fc.assemble_video(enc)
+        if world > 1:  # one process per GPU: intra-period units over the ranks, the container on rank 0
+            blob, enc = parallel.encode_video_sharded(fc, frames, gop_name, first, idx_rate=get_value('idx_rate', param, default),
+                                                      return_enc=True)
+        else:
+            enc = fc.encode_video(frames, gop_name, idx_starting_frame=first, idx_end_frame=last,
+                                  idx_rate=get_value('idx_rate', param, default))
+            blob = fc.assemble_video(enc)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    parent = os.path.dirname(final_file)
-    if parent:
-        os.makedirs(parent, exist_ok=True)
-    with open(final_file, 'wb') as f:
-        f.write(blob)
     n = last - first + 1
-    recs = [r for g in enc['recs'] for r in g][:n]
+    # squared error of the frames THIS process reconstructed (all of them on one GPU), summed over the ranks
+    se = cnt = 0.0
+    mine = []  # (absolute frame index, reconstruction)
+    for u, g in enumerate(enc['recs']):
+        if g is None:
+            continue
+        for i, r in enumerate(g):
+            idx = u * len(g) + i
+            if idx < n:
+                mine.append((first + idx, r))
+                se += sum(float(((r[k].float() - frames[idx][k].float()) ** 2).sum()) for k in 'yuv')
+                cnt += sum(frames[idx][k].numel() for k in 'yuv')
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([se, cnt], dtype=torch.float64, device=parallel._comm_device(None, dev))
+        dist.all_reduce(t)
+        se, cnt = float(t[0]), float(t[1])
     if get_value('flag_bitstream_debug', param, default):
         from .decode import debug_dir, write_debug_md5
-        write_debug_md5(recs, first, debug_dir(final_file))
-    se = sum(float(((r[k].float() - f[k].float()) ** 2).sum()) for r, f in zip(recs, frames) for k in 'yuv')
-    cnt = sum(f[k].numel() for f in frames for k in 'yuv')
+        for idx, r in mine:  # every rank writes the digests of its own frames
+            write_debug_md5([r], idx, debug_dir(final_file))
+    if rank == 0:
+        parent = os.path.dirname(final_file)
+        if parent:
+            os.makedirs(parent, exist_ok=True)
+        with open(final_file, 'wb') as f:
+            f.write(blob)
+    if world > 1:
+        dist.barrier()  # the file exists before any rank goes on (to decode it)
+    if rank != 0:
+        return None
     psnr = 10 * np.log10(255.0 ** 2 / max(se / cnt, 1e-12))
     print_log_msg('INFO', 'Encoding done', '', '')
     print_log_msg('INFO', 'Bitstream path', '', final_file)

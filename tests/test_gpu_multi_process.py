@@ -14,6 +14,12 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def _setup(n_units, gop, w=80, h=48):
     from aivc_amd import synth
     from aivc_amd.func_util.GOP_structure import generate_gop_struct
@@ -153,3 +159,35 @@ def test_gather_bytes_device_side_plumbing(cuda, monkeypatch):
     want = dict(mine)
     want.update(theirs)
     assert out == want and calls == [torch.int64, torch.uint8]
+
+
+def test_cli_two_ranks_equals_one_process(cuda, tmp_path):
+    """aivc.py under `torch.distributed.run` with two ranks (intra-period units sharded, rank 0 writes the files and
+    evaluates): bitstream and decoded .yuv are byte-identical to the single-process run, and the four evaluate lines
+    are printed once.  Both ranks sit on the box's one GPU over gloo (RCCL refuses two ranks per device)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from aivc_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w, h, n = 96, 64, 10  # RA 2/4: three intra-period units of 5, 4 and (padded) 1 frames
+    raw = tmp_path / ('clip_%dx%d_30_420.yuv' % (w, h))
+    with open(raw, 'wb') as f:
+        for fr in synth.synthetic_video(w, h, n):
+            for k in 'yuv':
+                f.write(fr[k].tobytes())
+    common = ['-i', str(raw), '--coding_config', 'RA', '--gop_size', '2', '--intra_period', '4', '--start_frame', '0',
+              '--end_frame', str(n - 1)]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    one = subprocess.run([sys.executable, '-m', 'aivc_amd.aivc'] + common + ['--bitstream_out', str(tmp_path / 'a.bin'), '-o', str(tmp_path / 'a.yuv')],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    port = _free_port()
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), '-m', 'aivc_amd.aivc'] + common + ['--bitstream_out', str(tmp_path / 'b.bin'), '-o', str(tmp_path / 'b.yuv')],
+                         cwd=str(tmp_path), env=dict(env, AIVC_DIST_BACKEND='gloo', AIVC_SINGLE_DEVICE='1'), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    assert (tmp_path / 'a.bin').read_bytes() == (tmp_path / 'b.bin').read_bytes()
+    assert np.array_equal(np.fromfile(tmp_path / 'a.yuv', np.uint8), np.fromfile(tmp_path / 'b.yuv', np.uint8))
+    pick = lambda out: [l for l in out.splitlines() if l.startswith(('PSNR    [dB]', 'MS-SSIM     ', 'MS-SSIM [dB]', 'Size [bytes]'))]
+    assert len(pick(two.stdout)) == 4 and pick(two.stdout) == pick(one.stdout)
