@@ -40,6 +40,7 @@ struct MfmaArgs {
   uint32_t cin_magic;  // ceil(2^32 / c_in): k / c_in == (k * magic) >> 32 for k < 2^16
   uint32_t w_magic, h_magic;  // floor(2^32 / w_in), floor(2^32 / h_in): quotient low by at most one
   int gx, gy;                  // pixel tiles, c_out tiles (the grid is 1-D: gx x gy x parity classes)
+  int tc_order;                // transposed conv: 1 = XCD-contiguous tile runs inside a parity class
 #ifdef AIVC_EXP_STAGGER
   int stagger, first_round;
 #endif
@@ -98,17 +99,26 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
   // round-robin to the 8 XCDs (each with a private 4 MiB L2); remap (bijectively) so that one XCD works on
   // a contiguous run of tiles, ordered so that neighbours share input: the c_out tiles of one pixel tile
   // first (same A rows), then the next pixel tile (shared halo rows).
-  // Transposed conv keeps the dispatch order, parity class slowest: its 4 classes have reductions of
-  // different length (9/6/6/4 taps for k = 5), so contiguous runs per XCD unbalance the XCDs, and
-  // interleaving the classes instead measured 25% slower as well (tools/bench_conv.py).
+  // Transposed conv: parity class slowest in dispatch order (its 4 classes have reductions of different length,
+  // 9/6/6/4 taps for k = 5: whole-grid contiguous runs per XCD would unbalance the XCDs), and INSIDE a class every
+  // XCD gets a contiguous run of the class's tiles (a.tc_order = 1, round 3: + 1 ... 2 % on the transposed layers;
+  // the vertical halo rows of neighbouring tiles meet in one L2).  Class fastest -- the four classes of a pixel tile
+  // back to back on one XCD -- measured 25 % slower, with the round-robin XCD deal and with contiguous runs alike.
   uint32_t tile_id = blockIdx.x;
+  const uint32_t per_class = (uint32_t)a.gx * (uint32_t)a.gy;
+  int bz = 0;
   if (MODE != AIVC_MODE_TCONV) {
     const uint32_t nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  } else {
+    bz = (int)(tile_id / per_class);
+    tile_id -= (uint32_t)bz * per_class;
+    if (a.tc_order == 1) {
+      // the workgroups of one XCD inside this class are those with the same (id within the class) & 7
+      const uint32_t l = tile_id, q = per_class >> 3, r = per_class & 7, v = l & 7;
+      tile_id = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (l >> 3);
+    }
   }
-  const uint32_t per_class = (uint32_t)a.gx * (uint32_t)a.gy;
-  const int bz = MODE == AIVC_MODE_TCONV ? (int)(tile_id / per_class) : 0;
-  if (MODE == AIVC_MODE_TCONV) tile_id -= (uint32_t)bz * per_class;
   const int by = (int)(tile_id % (uint32_t)a.gy), bx = (int)(tile_id / (uint32_t)a.gy);
   const int m0 = bx * BM, n0 = by * BN;
   const int ks = p.ksize, Cin = p.c_in, H = p.h_in, W = p.w_in, Cout = p.c_out;
@@ -1108,6 +1118,8 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   a.h_magic = p.h_in > 1 ? (uint32_t)(0x100000000ull / (uint64_t)p.h_in) : 0xFFFFFFFFu;
   a.gx = (a.M + BM - 1) / BM;
   a.gy = (p.c_out + BN - 1) / BN;
+  static const int tc_order = getenv("AIVC_TCONV_ORDER") ? atoi(getenv("AIVC_TCONV_ORDER")) : 1;  // tuning aid: 0 = plain dispatch order
+  a.tc_order = tc_order;
   dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
 #ifdef AIVC_EXP_STAGGER
   {
