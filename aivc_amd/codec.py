@@ -35,7 +35,7 @@ class FrameCodec:
     measured 2.3 % faster than 8 at 1080p -- fewer, larger launches: less drain / ramp time between the
     ~12 k stream-ordered kernels of a step -- 32 adds 0.4 %)."""
 
-    def __init__(self, full_net, max_batch=16, entropy_chunk=64, entropy_streams=4, entropy_lookahead=2,
+    def __init__(self, full_net, max_batch=16, entropy_chunk=64, entropy_streams=8, entropy_lookahead=2,
                  flag_md5sum=False):
         self.net = full_net
         self.entropy_chunk = entropy_chunk

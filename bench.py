@@ -35,6 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import aivc_amd  # noqa: E402,F401  (first: sets the runtime's hardware-queue count before the GPU is touched)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
@@ -55,6 +56,8 @@ def variant_name(v):
         return 'thin_mfma_kernel'
     if v == 190:
         return 'conv_mfma<conv,128x64+tail1x1>'
+    if v == 191:
+        return 'conv_images<4x32px,64+gdn>'
     c = v - 100
     fused = c >= 50
     c -= 50 if fused else 0
@@ -220,7 +223,7 @@ def main():
     ap.add_argument('--scaling', choices=('auto', 'strong', 'weak'), default=os.environ.get('AIVC_BENCH_SCALING', 'auto'),
                     help='auto = strong (one clip over all GPUs) when N > 1')
     ap.add_argument('--max-batch', type=int, default=64, help='frames of one dependency level per launch (64 = the widest level of the clip in one batch: +0.9 %% over 16, same-box A/B)')
-    ap.add_argument('--entropy-streams', type=int, default=4, help='decoder: concurrent range-coder chains')
+    ap.add_argument('--entropy-streams', type=int, default=8, help='decoder: concurrent range-coder chains')
     ap.add_argument('--entropy-lookahead', type=int, default=2, help='decoder: dependency levels of entropy decoding issued ahead')
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
