@@ -65,10 +65,13 @@ class FrameCodec:
         # lazy: the first conv reads the sources itself (aivc_conv_images); packed only if a layer cannot
         return ops.ImageStack(parts, h, w, device)
 
-    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
+    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False, on_sections=None):
         """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts
         (prev/nxt ignored where the frame type has no such reference).
-        -> list of {'bytes', 'rec', 'data_dim'[, 'aux']}"""
+        -> list of {'bytes', 'rec', 'data_dim'[, 'aux']}
+        on_sections(sections): called once every latent of the batch is quantised -- BEFORE the CodecNet synthesis is
+        queued -- so that the caller can send the non-zero-map flags on their way to the host (prepare_finalize)
+        half a batch earlier than the reconstructions exist."""
         n = len(cur)
         h, w = cur[0]['y'].shape[-2:]
         dev = cur[0]['y'].device
@@ -83,19 +86,21 @@ class FrameCodec:
             next444 = self.to444(next_p) if next_p is not None else torch.zeros_like(prev444)
             a = self.mof.analyse(self._images((cur_p, prev_p, next_p), h, w, dev), frame_type, idx_rate)
             short_in = self._images((prev_p, next_p), h, w, dev) if frame_type == FRAME_B else None
+            for i, (sz, sy) in enumerate(zip(self.mof.ac.pend_z(a['q_z']), self.mof.ac.pend_y(a['q_y'], a['sigma']))):
+                sections[i][0], sections[i][1] = sz, sy
             mof_out = self.mof.synthesise(a['y_hat'], short_in)
             wb = ops.warp_blend(mof_out, prev444, next444, h, w, frame_type, co=4, want_aux=want_aux)
             pred, skip = wb['pred'], wb['skip']
             pred._aivc_cmap = (0, 1, 2)  # 3 real channels + a zero pad channel
-            for i, (sz, sy) in enumerate(zip(self.mof.ac.pend_z(a['q_z']), self.mof.ac.pend_y(a['q_y'], a['sigma']))):
-                sections[i][0], sections[i][1] = sz, sy
             if want_aux:
                 aux.update(alpha=wb['alpha'], beta=wb['beta'], warping=wb['x_warp'][..., :3])
         c = self.cod.analyse(self._images((cur_p, pred), h, w, dev), frame_type, idx_rate)
-        cod_out = self.cod.synthesise(c['y_hat'], pred)
-        _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         for i, (sz, sy) in enumerate(zip(self.cod.ac.pend_z(c['q_z']), self.cod.ac.pend_y(c['q_y'], c['sigma']))):
             sections[i][2], sections[i][3] = sz, sy
+        if on_sections is not None:
+            on_sections(sections)
+        cod_out = self.cod.synthesise(c['y_hat'], pred)
+        _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         data_dim = {'x': (h, w), 'y': c['dim_y'], 'z': c['dim_z'],
                     'x_uv': (math.ceil(h / 2), math.ceil(w / 2))}
         recs = _unstack(dict(zip('yuv', rec8)), n)
@@ -207,34 +212,37 @@ class FrameCodec:
         data_dim = None
         sides = self._side_streams(self.entropy_streams)
         jobs = []
-        waiting = None  # (items, sections, flags on their way to the host) of the previous level
+        waiting = None  # [(items, sections, flags on their way to the host) per batch] of the previous level
         split = shard is not None and shard.R > 1
 
         def flush(li):
             # the levels' coder launches are independent of each other: rotate the stream so that a level with
             # long streams (few frames, big latents) does not queue the following ones behind it
             k = li % len(sides)
-            jobs.append((waiting[0], launch_finalize(waiting[1], sides[k], prepared=waiting[2],
-                                                     fork_streams=sides[k + 1:] + sides[:k])))
+            for items, secs, prep in waiting:
+                jobs.append((items, launch_finalize(secs, sides[k], prepared=prep,
+                                                    fork_streams=sides[k + 1:] + sides[:k])))
 
         n_levels = 0
         for li, level in enumerate(coding_levels(gop)):
             n_levels = li + 1
             pending = []
             for ftype, chunk in self._chunks(gop, level, range(len(units)), shard):
+                # the flags of the batch start their trip to the host as soon as its latents are quantised, i.e.
+                # before its CodecNet synthesis is queued: the LAST level's range coding then runs under that level's
+                # own synthesis instead of after it (it was the exposed tail of the encoder)
+                preps = []
                 out = self.encode_batch([units[u][frame_index(f)] for u, f in chunk],
                                         [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
-                                        [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate)
+                                        [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate,
+                                        on_sections=lambda secs: preps.append(prepare_finalize(secs)))
                 data_dim = out['data_dim']
                 for (u, f), r in zip(chunk, out['rec']):
                     rec[u][f] = r
-                pending.append((chunk, out['sections']))
-            # entropy coding runs on the side streams one level behind the transforms: the flags of THIS level
-            # start their trip to the host now, the host picks them up (and launches the range coder) only
-            # after the next level's transforms are queued, so the main stream never drains on that wait
-            all_secs = [s for _, secs in pending for s in secs]
-            items = [it for chunk, _ in pending for it in chunk]
-            prep = prepare_finalize(all_secs) if all_secs else None
+                pending.append((chunk, out['sections'], preps[0]))
+            # entropy coding runs on the side streams one level behind the transforms: the host picks the flags
+            # up (and launches the range coder) only after the next level's transforms are queued, so the main
+            # stream never drains on that wait
             if split:  # every rank of the group needs this level's reconstructions before the next level
                 h, w = units[0][0]['y'].shape[-2:]
                 for ftype in sorted({gop[f]['type'] for f in level}):
@@ -245,7 +253,7 @@ class FrameCodec:
                         rec[u][f] = r
             if waiting is not None:
                 flush(li - 1)
-            waiting = (items, all_secs, prep) if all_secs else None
+            waiting = pending if pending else None
         if waiting is not None:
             flush(n_levels - 1)
         for items, job in jobs:
