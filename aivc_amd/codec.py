@@ -7,6 +7,7 @@ references are exact: the reference casts every reconstruction to 8-bit levels, 
 """
 import contextlib
 import math
+import os as _os
 
 import torch
 
@@ -287,8 +288,13 @@ class FrameCodec:
             # synthesis stage on the main stream; the host alternates between the two so that both
             # queues stay fed
             main, sides = torch.cuda.current_stream(), self._side_streams(self.entropy_streams)
-            for sd in sides:
-                sd.wait_stream(main)
+            # The entropy stage depends on the bitstream (host memory) and on the model only -- never on what the main
+            # stream is still doing (in encode -> decode sequences: the last level's synthesis of the encoder), so the
+            # side streams do NOT wait for it: the first levels' serial y streams decode under that work.  (Kernel-
+            # ready parameters are synchronised when they are built, layers/_cache.py.)
+            if _os.environ.get('AIVC_DEC_WAIT_MAIN'):
+                for sd in sides:
+                    sd.wait_stream(main)
             levels = coding_levels(gop)
             lat, ready = {}, {}
             rr = [0]

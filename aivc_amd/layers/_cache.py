@@ -13,6 +13,12 @@ def cached(module, key, params, builder):
     if hit is not None and hit[0] == stamp:
         return hit[1]
     val = builder()
+    # built once per module (and after a parameter update): the packing kernels ran on the CURRENT stream, the value
+    # is then read from any stream (the codec's entropy stages run on side streams) -- one host wait here instead
+    # of stream bookkeeping at every use
+    import torch
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
     slot[key] = (stamp, val)
     return val
 

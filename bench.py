@@ -296,28 +296,33 @@ def main():
     # strong: every rank holds the same clips; weak: rank r codes clips r, r + world, ...
     clips = [make_clip(i if strong else rank + i * world) for i in range(n_total)]
     torch.cuda.synchronize()
-    stats = {'enc_s': 0.0, 'dec_s': 0.0, 'bytes': 0}
+    stats = {'enc_s': 0.0, 'dec_s': 0.0, 'bytes': 0, 'events': []}
 
     def step(clip, timed=False, sh=None):
-        """encode then decode one clip -> (gop records, data_dim, {unit: reconstructions of the encoder}, decoded)"""
+        """encode then decode one clip -> (gop records, data_dim, {unit: reconstructions of the encoder}, decoded).
+        No host synchronisation inside a timed step: the decoder's entropy stage (side streams; it needs the bitstream
+        only) starts while the main stream still runs the encoder's last synthesis.  The encode / decode split of a
+        step is read from events on the main stream after the run."""
         with torch.no_grad():
-            t0 = time.time()
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             if sh is not None:
                 blobs, dd = parallel.encode_clip(fc, clip, args.gop, shard=sh)
                 enc_recs = None
             else:
                 blobs, enc_recs, dd = fc.encode_units(clip, args.gop)
             if timed:
-                torch.cuda.synchronize()
-                t1 = time.time()
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
             if sh is not None:
                 dec = parallel.decode_clip(fc, blobs, dd, dev, shard=sh)
             else:
                 dec = dict(enumerate(fc.decode_units(blobs, dd, dev)))
             if timed:
-                torch.cuda.synchronize()
-                stats['enc_s'] += t1 - t0
-                stats['dec_s'] += time.time() - t1
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record()
+                stats['events'].append((e0, e1, e2))
                 stats['bytes'] += sum(len(b) for b in blobs)
         return blobs, dd, enc_recs, dec
 
@@ -334,6 +339,10 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.time() - t0
+        for e0, e1, e2 in stats['events']:  # main-stream time of the two halves of every step
+            stats['enc_s'] += e0.elapsed_time(e1) * 1e-3
+            stats['dec_s'] += e1.elapsed_time(e2) * 1e-3
+        del stats['events'][:]
         if use_dist:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
