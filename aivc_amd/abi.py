@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -99,6 +99,7 @@ PROTOTYPES = {
     'aivc_dequantize': [_f, _f, _f, _sz, _i32, _f],
     'aivc_balle_cdf_table': [_f, _i32, _f, _f],
     'aivc_nonzero_maps': [_f, _sz, _i32, _f],
+    'aivc_nonzero_maps_batch': [_f, _i32, _sz, _i32, _f],
     'aivc_laplace_cdf_rows': [_f, _sz, _i32, _P(MapList), _f],
     'aivc_laplace_cdf_windows': [_f, _sz, _i32, _P(MapList), _f, _f],
     'aivc_laplace_bounds': [_f, _f, _sz, _i32, _P(MapList), _f],

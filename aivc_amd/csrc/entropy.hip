@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void balle_cdf_table_kernel(const float *__res
 // ------------------------------------------------------------------ non-zero feature maps
 __global__ __launch_bounds__(256) void nonzero_maps_kernel(const int16_t *__restrict__ q, size_t npix, int c,
                                                            uint8_t *__restrict__ flags) {
+  // grid.y = image of a batch: q is [n][npix][c], flags [n][c]
+  q += (size_t)blockIdx.y * npix * c;
+  flags += (size_t)blockIdx.y * c;
   // every writer stores the same value (1): deterministic without atomics
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * c; i += (size_t)gridDim.x * blockDim.x)
     if (q[i] != 0) flags[i % c] = 1;
@@ -538,14 +541,19 @@ AIVC_EXPORT int aivc_balle_cdf_table(const float *params, int32_t c, uint16_t *t
   return check_launch("balle_cdf_table");
 }
 
-AIVC_EXPORT int aivc_nonzero_maps(const int16_t *q, size_t npix, int32_t c, uint8_t *flags, aivc_stream_t stream) {
-  if (!q || !flags || c <= 0 || c > AIVC_MAX_MAPS) return AIVC_ERR_ARG;
-  if (hipMemsetAsync(flags, 0, c, to_stream(stream)) != hipSuccess) return check_launch("nonzero_maps memset");
+AIVC_EXPORT int aivc_nonzero_maps_batch(const int16_t *q, int32_t n, size_t npix, int32_t c, uint8_t *flags,
+                                        aivc_stream_t stream) {
+  if (!q || !flags || c <= 0 || c > AIVC_MAX_MAPS || n <= 0 || n > 65535) return AIVC_ERR_ARG;
+  if (hipMemsetAsync(flags, 0, (size_t)n * c, to_stream(stream)) != hipSuccess) return check_launch("nonzero_maps memset");
   if (npix == 0) return AIVC_OK;
   unsigned grid = cdiv(npix * c, 256 * 8);
   grid = grid > 2048 ? 2048 : (grid == 0 ? 1 : grid);
-  hipLaunchKernelGGL(nonzero_maps_kernel, dim3(grid), dim3(256), 0, to_stream(stream), q, npix, c, flags);
+  hipLaunchKernelGGL(nonzero_maps_kernel, dim3(grid, (unsigned)n), dim3(256), 0, to_stream(stream), q, npix, c, flags);
   return check_launch("nonzero_maps");
+}
+
+AIVC_EXPORT int aivc_nonzero_maps(const int16_t *q, size_t npix, int32_t c, uint8_t *flags, aivc_stream_t stream) {
+  return aivc_nonzero_maps_batch(q, 1, npix, c, flags, stream);
 }
 
 static int check_maps(const aivc_map_list *maps, int c) {

@@ -480,8 +480,9 @@ def nonzero_flags(q):
     n, c = q.shape[0], q.shape[-1]
     npix = q.numel() // (n * c)
     flags = torch.empty((n, c), dtype=torch.uint8, device=q.device)
-    for i in range(n):
-        call('aivc_nonzero_maps', q.data_ptr() + 2 * i * npix * c, npix, c, flags.data_ptr() + i * c, _stream())
+    for i0 in range(0, n, 65535):  # one launch for the whole batch (grid.y = image)
+        m = min(65535, n - i0)
+        call('aivc_nonzero_maps_batch', q.data_ptr() + 2 * i0 * npix * c, m, npix, c, flags.data_ptr() + i0 * c, _stream())
     return flags
 
 

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 8 */
+int aivc_abi_version(void); /* currently 9 */
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 
@@ -282,6 +282,9 @@ int aivc_balle_cdf_table(const float *params, int32_t c, uint16_t *table, float 
  * q is [h*w][c] int16; flags[c] gets 0/1 (device). */
 int aivc_nonzero_maps(const int16_t *q, size_t npix, int32_t c, uint8_t *flags,
                       aivc_stream_t stream);
+/* The same for the n images of a batch in one launch (ABI 9): q [n][h*w][c], flags [n][c]; n <= 65535. */
+int aivc_nonzero_maps_batch(const int16_t *q, int32_t n, size_t npix, int32_t c, uint8_t *flags,
+                            aivc_stream_t stream);
 
 typedef struct aivc_map_list {
   int32_t n_maps;

@@ -192,6 +192,13 @@ def test_cdf_kernels_bit_exact(oracle, cuda):
     eq(ops.table_bounds(T(table.view(np.int16), cuda), T(qz, cuda)), oracle.table_bounds(table, qz))
     flags = ops.nonzero_flags(T(q, cuda)).cpu().numpy()[0]
     assert [i for i in range(8) if flags[i]] == oracle.nonzero_maps(q)
+    # the frames of a batch in one launch: every image has its own set of all-zero maps
+    qb = np.clip(np.rint(rng.laplace(0, 1, (5, 6, 7, 8)) * 3), -256, 255).astype(np.int16)
+    for i, dead in enumerate(([], [0], [1, 7], list(range(8)), [3])):
+        qb[i][..., dead] = 0
+    fb = ops.nonzero_flags(T(qb, cuda)).cpu().numpy()
+    for i in range(5):
+        assert [k for k in range(8) if fb[i][k]] == oracle.nonzero_maps(qb[i:i + 1])
 
 
 @pytest.mark.parametrize('n_sym,scale', [(1, 1.0), (63, 0.3), (64, 2.0), (65, 5.0), (1000, 0.05), (5000, 1.0),
