@@ -230,15 +230,51 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
   // A fragments: corner (LO, LO) of the neighbourhood of this lane's pixel; steps add constant offsets
   const int a_off = ((row + 1 + LO) * PW + 1 + LO + mg0 * 16 + col) * SPX + 4 * g;
 
+  // ---- epilogue of one tile: lane (col, g) holds rows 4 g + r of its 16-pixel groups ------------------------
+  auto emit = [&](int etile, const floatx4 (&eacc)[NMG]) {
+    int n, ty0, tx0;
+    tile_origin(etile, n, ty0, tx0);
+    const int qy = ty0 + row;
+    if (colok && qy < H) {
+#pragma unroll
+      for (int mg = 0; mg < NMG; ++mg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qx = tx0 + (mg0 + mg) * 16 + 4 * g + r;
+          if (qx < W) {
+            const size_t off = (((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc)) * CO + o;
+            float v = eacc[mg][r];
+            if (has_bias) v = v + bias_o;
+            v = v > 0.0f ? v : (act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v));
+            if (p.mul) v = p.mul[off] * v;
+            if (p.res) v = v + p.res[off];
+            v = v > 0.0f ? v : (act2 == AIVC_ACT_LEAKY ? v * 0.01f : (act2 == AIVC_ACT_RELU ? 0.0f : v));
+            p.y[off] = v;
+          }
+        }
+    }
+  };
+
+  // Software pipeline over the tiles of this workgroup (round 3): the reduction of a tile is one dependent chain of
+  // 16x16x4 MFMAs per 16-pixel group -- 32 cycles each with nothing else to issue -- so the epilogue of the PREVIOUS
+  // tile (its accumulators are 4 registers per group) and the LDS stores of the NEXT tile's patch sit inside that
+  // chain instead of between two chains, where all 8 wavefronts of the CU left the matrix pipe idle together.
+  //   patch(next) -> registers (global loads in flight for a whole tile) -> LDS buffer cur ^ 1 at step STORE_AT of
+  //   this tile's chain (its last readers passed the barrier at the end of the previous tile); one barrier per tile.
+  constexpr int EMIT_AT = NSTEP > 8 ? 2 : 0, STORE_AT = NSTEP > 8 ? NSTEP * 2 / 3 : NSTEP - 1;
   int tile = blockIdx.x, cur = 0;
   if (tile < ntiles) {
     stage_load(tile);
     stage_store(smem);
   }
   __syncthreads();
+  if (tile + (int)gridDim.x < ntiles) stage_load(tile + gridDim.x);
+  floatx4 pacc[NMG];
+#pragma unroll
+  for (int mg = 0; mg < NMG; ++mg) pacc[mg] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  int ptile = -1;
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
-    if (next < ntiles) stage_load(next);
     const float *ap = smem + cur * PATCH + a_off;
     floatx4 acc[NMG];
 #pragma unroll
@@ -251,6 +287,11 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
 #pragma unroll
       for (int mg = 0; mg < NMG; ++mg)
         af[mg] = *reinterpret_cast<const float4 *>(ap + ((dy - LO) * PW + (dx - LO) + mg * 16) * SPX + j16 * 16);
+      if (step == EMIT_AT && ptile >= 0) emit(ptile, pacc);
+      if (step == STORE_AT && next < ntiles) {
+        stage_store(smem + (cur ^ 1) * PATCH);
+        if (next + (int)gridDim.x < ntiles) stage_load(next + gridDim.x);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -259,34 +300,13 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
           acc[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[step][e], acc[mg], 0, 0, 0);
         }
     }
-    // ---- epilogue: lane (col, g) holds rows 4 g + r of its 16-pixel groups ---------------------------
-    {
-      int n, ty0, tx0;
-      tile_origin(tile, n, ty0, tx0);
-      const int qy = ty0 + row;
-      if (colok && qy < H) {
 #pragma unroll
-        for (int mg = 0; mg < NMG; ++mg)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qx = tx0 + (mg0 + mg) * 16 + 4 * g + r;
-            if (qx < W) {
-              const size_t off = (((size_t)n * p.h_out + (2 * qy + pyc)) * p.w_out + (2 * qx + pxc)) * CO + o;
-              float v = acc[mg][r];
-              if (has_bias) v = v + bias_o;
-              v = v > 0.0f ? v : (act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v));
-              if (p.mul) v = p.mul[off] * v;
-              if (p.res) v = v + p.res[off];
-              v = v > 0.0f ? v : (act2 == AIVC_ACT_LEAKY ? v * 0.01f : (act2 == AIVC_ACT_RELU ? 0.0f : v));
-              p.y[off] = v;
-            }
-          }
-      }
-    }
-    if (next < ntiles) stage_store(smem + (cur ^ 1) * PATCH);
+    for (int mg = 0; mg < NMG; ++mg) pacc[mg] = acc[mg];
+    ptile = tile;
     __syncthreads();
     cur ^= 1;
   }
+  if (ptile >= 0) emit(ptile, pacc);
 }
 
 static bool thin_mfma_ok(const aivc_conv_params &p) {
