@@ -243,7 +243,9 @@ def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
     y, u, v = _dev(y, dt, 'y'), _dev(u, dt, 'u'), _dev(v, dt, 'v')
     n, h, w = y.shape
     if out is None:
-        out = torch.zeros((n, h, w, c_store), dtype=torch.float32, device=y.device)
+        # the kernel writes channels c_off .. c_off + 2 (+ the zero pad channel): nothing else to clear when that is all
+        full = c_off == 0 and c_store <= 4
+        out = (torch.empty if full else torch.zeros)((n, h, w, c_store), dtype=torch.float32, device=y.device)
     zero_pad = 1 if out.shape[-1] >= c_off + 4 else 0
     hc, wc = (h + 1) // 2, (w + 1) // 2
     _hbm_profiled('yuv420_to_444', n * ((h * w + 2 * hc * wc) * (1 if u8 else 4) + h * w * 4 * (3 + zero_pad)),

@@ -96,7 +96,7 @@ def test_conv_family_bit_exact(case, algo, oracle, cuda):
 def test_frame_ops_bit_exact(oracle, cuda):
     from aivc_amd import ops
     rng = np.random.default_rng(5)
-    for (h, w) in [(9, 13), (10, 14), (16, 16), (1, 1)]:
+    for (h, w) in [(9, 13), (10, 14), (16, 16), (1, 1), (6, 1028)]:
         hc, wc = (h + 1) // 2, (w + 1) // 2
         y8 = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
         u8 = rng.integers(0, 256, (2, hc, wc), dtype=np.uint8)
@@ -112,6 +112,17 @@ def test_frame_ops_bit_exact(oracle, cuda):
             rf, rb = oracle.frame_to_yuv420(x, h, w, skip=sk)
             gf, gb = ops.frame_to_yuv420(T(x, cuda), h, w, skip=None if sk is None else T(sk, cuda))
             for a, b in zip(gf + gb, rf + rb):
+                eq(a, b)
+        # the synthesis output as the codec hands it over: 3 channels, padded to an even row length (the 8-byte /
+        # 16-byte load path of the kernel when the frame sides are even, the scalar one otherwise)
+        x3 = np.ascontiguousarray(x[:, :, :w + 2 - (w & 1), :3])
+        for sk in (None, skip):
+            rf, rb = oracle.frame_to_yuv420(x3, h, w, skip=sk)
+            gf, gb = ops.frame_to_yuv420(T(x3, cuda), h, w, skip=None if sk is None else T(sk, cuda))
+            for a, b in zip(gf + gb, rf + rb):
+                eq(a, b)
+            _, gb8 = ops.frame_to_yuv420(T(x3, cuda), h, w, skip=None if sk is None else T(sk, cuda), want_float=False)
+            for a, b in zip(gb8, rb):
                 eq(a, b)
 
 
