@@ -12,13 +12,18 @@ def cached(module, key, params, builder):
     hit = slot.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
-    val = builder()
-    # built once per module (and after a parameter update): the packing kernels ran on the CURRENT stream, the value
-    # is then read from any stream (the codec's entropy stages run on side streams) -- one host wait here instead
-    # of stream bookkeeping at every use
+    # (Re)built once per module and parameter version.  The codec reads kernel-ready parameters from several
+    # streams (its entropy stages run on side streams that do not wait for the main stream, codec.py), so both ends
+    # are closed with a device-wide wait instead of stream bookkeeping at every use: BEFORE, whatever wrote the
+    # parameters (an H2D copy, an initialiser, a broadcast -- on any stream) has finished; AFTER, the packing kernels
+    # (launched on the current stream) have.
     import torch
-    if torch.cuda.is_available() and torch.cuda.is_initialized():
-        torch.cuda.current_stream().synchronize()
+    gpu = torch.cuda.is_available() and torch.cuda.is_initialized()
+    if gpu:
+        torch.cuda.synchronize()
+    val = builder()
+    if gpu:
+        torch.cuda.synchronize()
     slot[key] = (stamp, val)
     return val
 

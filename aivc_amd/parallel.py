@@ -28,6 +28,8 @@ def broadcast_model(model, src=0):
     # cache is stamped with: anything cached before the broadcast would stay stale on the receiving ranks
     from .layers import _cache
     _cache.clear()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()  # the codec's side streams read the parameters without waiting for this stream
     return model
 
 
