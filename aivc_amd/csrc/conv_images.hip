@@ -151,15 +151,19 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       const int iy = min(max(2 * oy0 - 2 + pr, 0), H - 1), ix = min(max(2 * ox0 - 2 + pc, 0), W - 1);
       const aivc_image_src &s = a.src[img];
       raw[i][0] = raw[i][1] = raw[i][2] = 0u;
+      // 32-bit element offsets off the (uniform) plane pointers: scalar base + vector offset addressing, no 64-bit
+      // address arithmetic per sample (conv_images_supported bounds the planes to 2^31 elements / 2^32 bytes)
       if (s.y) {
-        raw[i][0] = s.y[((size_t)b * H + iy) * W + ix];
-        raw[i][1] = s.u[((size_t)b * hc + (iy >> 1)) * wc + (ix >> 1)];
-        raw[i][2] = s.v[((size_t)b * hc + (iy >> 1)) * wc + (ix >> 1)];
+        const uint32_t oy = ((uint32_t)b * (uint32_t)H + (uint32_t)iy) * (uint32_t)W + (uint32_t)ix;
+        const uint32_t oc = ((uint32_t)b * (uint32_t)hc + (uint32_t)(iy >> 1)) * (uint32_t)wc + (uint32_t)(ix >> 1);
+        raw[i][0] = s.y[oy];
+        raw[i][1] = s.u[oc];
+        raw[i][2] = s.v[oc];
       } else if (s.f) {
-        const float *f = s.f + (((size_t)b * H + iy) * W + ix) * s.f_channels;
-        raw[i][0] = __float_as_uint(f[0]);
-        raw[i][1] = __float_as_uint(f[1]);
-        raw[i][2] = __float_as_uint(f[2]);
+        const uint32_t of = (((uint32_t)b * (uint32_t)H + (uint32_t)iy) * (uint32_t)W + (uint32_t)ix) * (uint32_t)s.f_channels;
+        raw[i][0] = __float_as_uint(s.f[of]);
+        raw[i][1] = __float_as_uint(s.f[of + 1u]);
+        raw[i][2] = __float_as_uint(s.f[of + 2u]);
       }
     }
   };
@@ -277,7 +281,13 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     // variant and the edge masking are chosen once per tile (uniform branch), not per element
     const int oy = oy0 + wave;
     if (oy < a.ho) {
-      float *yrow = a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO + p;
+      // wave-uniform row base (scalar registers) + one 32-bit lane offset: the 32 store addresses of a lane are
+      // immediates off it (as 64-bit per-element pointers they were what the kernel spilled)
+      const uint64_t yb64 = (uint64_t)(uintptr_t)(a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO);
+      const uint32_t yb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(yb64 >> 32));  // (the builtin returns int:
+      const uint32_t yb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)yb64);          //  no sign extension)
+      float *yrow = reinterpret_cast<float *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
+      const uint32_t lane_off = (uint32_t)(4 * hh * IC_CO + p);
       const int cols = a.wo - ox0;  // output columns of this tile that exist (>= 1)
       auto emit = [&](auto MODE, auto WHOLE) {
         constexpr int MD = decltype(MODE)::value;  // 0 / 1 / 2: no GDN + none / leaky / relu, 3: GDN, 4: inverse GDN
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int mc = (r & 3) + 8 * (r >> 2);  // compile-time after unrolling
+            const int m = mc + 4 * hh;
             float v = acc[j][r];
             if constexpr (MD >= 3) {
               const float nrm = __builtin_sqrtf(acc2[j][r] + cbeta[j]);
@@ -294,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
             }
             if constexpr (MD == 1) v = v > 0.0f ? v : v * 0.01f;
             if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
-            if (WH || m < cols) yrow[(size_t)m * IC_CO + 32 * j] = v;
+            if (WH || m < cols) yrow[lane_off + (uint32_t)(mc * IC_CO + 32 * j)] = v;
             // keep the elements apart: interleaved sqrt / division sequences of many of them cost registers (the
-            // gamma fragments already take 64)
+            // gamma fragments already take 64); a barrier every 2 / 4 / 16 elements measured the same
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -341,6 +352,11 @@ bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv
   if (p.mul || p.res || p.act2 != AIVC_ACT_NONE || p.tail_c_out) return false;
   if (p.gdn ? p.act1 != AIVC_ACT_NONE : p.act1 == AIVC_ACT_SIGMOID) return false;
   if ((uint64_t)p.n * ((p.h_out + IC_TH - 1) / IC_TH) * ((p.w_out + IC_TW - 1) / IC_TW) >= 0x7FFFFFFFull) return false;
+  // 32-bit sample offsets in the kernel: float sources up to 2^32 bytes, 8-bit planes far below
+  for (int i = 0; i < n_img; ++i) {
+    const uint64_t elems = (uint64_t)p.n * p.h_in * p.w_in * (src[i].y ? 1 : (src[i].f ? src[i].f_channels : 0));
+    if (elems >= (src[i].y ? 0x7FFFFFFFull : 0x3FFFFFFFull)) return false;
+  }
   return true;
 }
 
