@@ -108,26 +108,51 @@ __global__ __launch_bounds__(256) void laplace_cdf_rows_kernel(const float *__re
 // this kernel produces just those (128 B per coded position instead of 1040) plus sigma of the position, from which
 // the decoder's slow path rebuilds the rest of a row on demand with the same function.
 constexpr int CDF_WIN0 = 224, CDF_WIN = 64;
+// A wavefront builds ONE 8-entry chunk (16 bytes) of the windows of 64 consecutive positions, so the saturation test
+// is wave-uniform: for the small sigmas of P / B latents the outer chunks of a window lie where the function returns
+// expm1 = -1 exactly (|t| / b > 17.5: cdf 0 or 1, entry k or 65023 + k) for every position of the wavefront, and
+// the fp64 evaluation is skipped for the whole wavefront (one diverging lane used to keep all 64 on the long path).
 __global__ __launch_bounds__(256) void laplace_cdf_windows_kernel(const float *__restrict__ sigma, size_t npix, int c,
                                                                   aivc_map_list maps, uint16_t *__restrict__ win,
                                                                   float *__restrict__ sigma_pos) {
   constexpr int CHUNKS = CDF_WIN / 8;  // 8 x 16 B per position
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)maps.n_maps * npix * CHUNKS;
-  if (gid >= total) return;
-  const int chunk = (int)(gid % CHUNKS);
-  const size_t pos = gid / CHUNKS;
-  const int m = (int)(pos / npix);
-  const size_t pix = pos % npix;
-  const float s = sigma[pix * c + maps.idx[m]];
-  if (chunk == 0) sigma_pos[pos] = s;
-  uint32_t w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k0 = CDF_WIN0 + chunk * 8 + 2 * j;
-    w[j] = (uint32_t)aivc_laplace_cdf_u16(k0, s) | ((uint32_t)aivc_laplace_cdf_u16(k0 + 1, s) << 16);
+  const size_t total = (size_t)maps.n_maps * npix;
+  const size_t wv = gid >> 6;
+  const int lane = (int)(gid & 63), chunk = (int)(wv % CHUNKS);
+  const size_t pos = (wv / CHUNKS) * 64 + (size_t)lane;
+  const bool valid = pos < total;
+  float s = 1.0f;
+  if (valid) {
+    const int m = (int)(pos / npix);
+    const size_t pix = pos % npix;
+    s = sigma[pix * c + maps.idx[m]];
+    if (chunk == 0) sigma_pos[pos] = s;
   }
-  *reinterpret_cast<uint4 *>(win + pos * CDF_WIN + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  const int k0 = CDF_WIN0 + chunk * 8;
+  uint32_t w[4];
+  // the entry of this chunk nearest to the centre decides: |t| / b is monotonic in |t| (correctly rounded division)
+  bool sat = false;
+  if (chunk != CHUNKS / 2) {  // (the chunk around t = 0 holds both signs)
+    const float tmin = chunk < CHUNKS / 2 ? 256.5f - (float)(k0 + 7) : (float)k0 - 256.5f;
+    const float b = s / 1.41421354f;  // as in aivc_laplace_cdf
+    sat = tmin / b > 17.5f;           // aivc_expm1f_det(-a) returns -1.0f for -a < -17.5f
+  }
+  if (__all(sat || !valid)) {
+    const uint32_t base = chunk < CHUNKS / 2 ? 0u : 65023u;  // rint(0 * 65023), rint(1 * 65023)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t k = (uint32_t)(k0 + 2 * j);
+      w[j] = ((base + k) & 0xFFFFu) | (((base + k + 1u) & 0xFFFFu) << 16);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 2 * j;
+      w[j] = (uint32_t)aivc_laplace_cdf_u16(k, s) | ((uint32_t)aivc_laplace_cdf_u16(k + 1, s) << 16);
+    }
+  }
+  if (valid) *reinterpret_cast<uint4 *>(win + pos * CDF_WIN + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __global__ __launch_bounds__(256) void laplace_bounds_kernel(const float *__restrict__ sigma,
@@ -161,14 +186,36 @@ __global__ __launch_bounds__(256) void table_bounds_kernel(const uint16_t *__res
 struct InvMap {
   int16_t slot[AIVC_MAX_MAPS];  // channel -> position in the coded list, or -1
 };
+// A thread writes 8 consecutive channels (16 bytes) of one pixel; consecutive lanes take consecutive pixels, so every
+// read of a coded map is 128 contiguous bytes per wavefront (one thread per (pixel, channel) with the channel
+// fastest read 64 different maps per load: 36 us for a 1080p latent).
 __global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__restrict__ sym, size_t npix, int c,
-                                                              InvMap inv, int16_t *__restrict__ q) {
+                                                              InvMap inv, int16_t *__restrict__ q, int vec) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= npix * c) return;
-  const int ch = (int)(gid % c);
-  const size_t pix = gid / c;
-  const int m = inv.slot[ch];
-  q[gid] = m < 0 ? (int16_t)0 : (int16_t)((int)sym[(size_t)m * npix + pix] - AIVC_AC_MAX_VAL);
+  const int groups = (c + 7) / 8;
+  if (gid >= npix * groups) return;
+  const size_t pix = gid % npix;
+  const int ch0 = (int)(gid / npix) * 8;
+  int16_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = ch0 + e;
+    const int m = ch < c ? inv.slot[ch] : -1;
+    v[e] = m < 0 ? (int16_t)0 : (int16_t)((int)sym[(size_t)m * npix + pix] - AIVC_AC_MAX_VAL);
+  }
+  int16_t *dst = q + pix * c + ch0;
+  if (vec) {  // c % 8 == 0 and q 16-byte aligned
+    uint4 o;
+    o.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+    o.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+    o.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
+    o.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+    *reinterpret_cast<uint4 *>(dst) = o;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ch0 + e < c) dst[e] = v[e];
+  }
 }
 
 // ------------------------------------------------------------------ range encoder
@@ -603,8 +650,9 @@ AIVC_EXPORT int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c
   InvMap inv;
   for (int i = 0; i < AIVC_MAX_MAPS; ++i) inv.slot[i] = -1;
   for (int i = 0; i < maps->n_maps; ++i) inv.slot[maps->idx[i]] = (int16_t)i;
-  hipLaunchKernelGGL(scatter_symbols_kernel, dim3(cdiv(npix * c, 256)), dim3(256), 0, to_stream(stream), sym, npix,
-                     c, inv, q);
+  const int vec = (c & 7) == 0 && ((uintptr_t)q & 15) == 0;
+  hipLaunchKernelGGL(scatter_symbols_kernel, dim3(cdiv(npix * ((c + 7) / 8), 256)), dim3(256), 0, to_stream(stream), sym, npix,
+                     c, inv, q, vec);
   return check_launch("scatter_symbols");
 }
 
@@ -631,8 +679,9 @@ AIVC_EXPORT int aivc_laplace_cdf_windows(const float *sigma, size_t npix, int32_
                                          uint16_t *win, float *sigma_pos, aivc_stream_t stream) {
   if (!sigma || !win || !sigma_pos || c <= 0) return AIVC_ERR_ARG;
   if (int rc = check_maps(maps, c)) return rc;
-  const size_t total = (size_t)maps->n_maps * npix * (CDF_WIN / 8);
-  if (total == 0) return AIVC_OK;
+  const size_t n_pos = (size_t)maps->n_maps * npix;
+  if (n_pos == 0) return AIVC_OK;
+  const size_t total = ((n_pos + 63) / 64) * (CDF_WIN / 8) * 64;  // a wavefront per (64 positions, chunk)
   hipLaunchKernelGGL(laplace_cdf_windows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, to_stream(stream), sigma, npix, c,
                      *maps, win, sigma_pos);
   return check_launch("laplace_cdf_windows");
