@@ -12,6 +12,7 @@
 //     class in (ky, kx) order, 8 channels at a time in AIVC_K_ORDER (include/aivc_hip.h); taps outside the
 //     image contribute fmaf(0, w, acc) = acc.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -231,7 +232,10 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
   const int a_off = ((row + 1 + LO) * PW + 1 + LO + mg0 * 16 + col) * SPX + 4 * g;
 
   // ---- epilogue of one tile: lane (col, g) holds rows 4 g + r of its 16-pixel groups ------------------------
-  auto emit = [&](int etile, const floatx4 (&eacc)[NMG]) {
+  // (the variant without gate / residual operands has no load in it: with them in the same code the compiler drains
+  // the memory counter -- the tile's own stores included -- after every element)
+  auto emit_v = [&](auto EXTRA, int etile, const floatx4 (&eacc)[NMG]) {
+    constexpr bool extra = decltype(EXTRA)::value;
     int n, ty0, tx0;
     tile_origin(etile, n, ty0, tx0);
     const int qy = ty0 + row;
@@ -246,13 +250,20 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
             float v = eacc[mg][r];
             if (has_bias) v = v + bias_o;
             v = v > 0.0f ? v : (act1 == AIVC_ACT_LEAKY ? v * 0.01f : (act1 == AIVC_ACT_RELU ? 0.0f : v));
-            if (p.mul) v = p.mul[off] * v;
-            if (p.res) v = v + p.res[off];
+            if constexpr (extra) {
+              if (p.mul) v = p.mul[off] * v;
+              if (p.res) v = v + p.res[off];
+            }
             v = v > 0.0f ? v : (act2 == AIVC_ACT_LEAKY ? v * 0.01f : (act2 == AIVC_ACT_RELU ? 0.0f : v));
             p.y[off] = v;
           }
         }
     }
+  };
+  const bool has_extra = p.mul != nullptr || p.res != nullptr;
+  auto emit = [&](int etile, const floatx4 (&eacc)[NMG]) {
+    if (has_extra) emit_v(std::true_type{}, etile, eacc);
+    else emit_v(std::false_type{}, etile, eacc);
   };
 
   // Software pipeline over the tiles of this workgroup (round 3): the reduction of a tile is one dependent chain of
@@ -261,6 +272,8 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
   // chain instead of between two chains, where all 8 wavefronts of the CU left the matrix pipe idle together.
   //   patch(next) -> registers (global loads in flight for a whole tile) -> LDS buffer cur ^ 1 at step STORE_AT of
   //   this tile's chain (its last readers passed the barrier at the end of the previous tile); one barrier per tile.
+  // (EMIT_AT 6 and STORE_AT at 1/3 or 1/2 of the chain measure the same; the epilogue in the middle or at the end of
+  // the chain -- EMIT_AT 12 / 20 of 36 -- runs TWICE as long)
   constexpr int EMIT_AT = NSTEP > 8 ? 2 : 0, STORE_AT = NSTEP > 8 ? NSTEP * 2 / 3 : NSTEP - 1;
   int tile = blockIdx.x, cur = 0;
   if (tile < ntiles) {
