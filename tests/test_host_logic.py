@@ -180,3 +180,29 @@ def test_bench_cli_parses():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and '--gpus' in (out.stdout + out.stderr) and '--active-y' in (out.stdout + out.stderr)
+
+
+def test_package_import_asks_for_eight_hardware_queues():
+    """the codec's 8 entropy side streams need as many hardware queues: the package sets the runtime's
+    variable at import unless the user already did -- checked in a fresh interpreter"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'import os, sys; sys.path.insert(0, %r); import aivc_amd; print(os.environ["GPU_MAX_HW_QUEUES"])' % root
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.stdout.strip() == '8', out.stderr
+    env['GPU_MAX_HW_QUEUES'] = '4'
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.stdout.strip() == '4', out.stderr
+
+
+def test_encode_batch_hands_sections_over_before_the_synthesis():
+    """FrameCodec.encode_batch(on_sections=...) exists and encode_units uses it (the flags of a batch leave for the
+    host before its CodecNet synthesis is queued): a source-level check, the behaviour is covered by the GPU tests"""
+    import inspect
+    from aivc_amd import codec
+    src = inspect.getsource(codec.FrameCodec.encode_batch)
+    assert src.index('on_sections(sections)') < src.index('self.cod.synthesise(')
+    assert 'on_sections=' in inspect.getsource(codec.FrameCodec.encode_units)
