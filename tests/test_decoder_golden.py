@@ -19,8 +19,10 @@ from oracle import spec as ospec
 
 # decoder_big_gop8: 200 x 136, hierarchical 1_GOP_8, 16 + 5 coded maps, z 3 x 4, h_s output cropped; the variants:
 # no shortcut transform + empty MOFNet y sections, no P / B gain matrices (tests/decoder_variants.py)
+# decoder_b_*: a second draw of the small model (another seed, 3 + 4 coded maps): 1_GOP_4 with a fractional rate index,
+# LDP_8 from frame 3 on an odd-sized frame
 CASES = ['decoder_ra', 'decoder_ra_chained', 'decoder_ldp_odd', 'decoder_big_gop8', 'decoder_noref_empty_y',
-         'decoder_gain_i']
+         'decoder_gain_i', 'decoder_b_gop4', 'decoder_b_ldp8']
 NAMES = ('mofnet', 'codecnet')
 
 

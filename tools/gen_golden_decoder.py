@@ -452,6 +452,8 @@ MODELS = {
     # every y map of CodecNet coded (the I frame's section lists all 16), wider latents, z of 3 x 4; weights on a
     # 2^-12 grid (they are arbitrary anyway; the zero mantissa bits halve the compressed fixture)
     'decoder_model_big': dict(widths=WIDTHS_BIG, active_y=(5, 16), weight_grid=4096.0),
+    # a second draw of the small model (other seed range, other number of coded maps) for two more coding structures
+    'decoder_model_b': dict(widths=WIDTHS, active_y=(3, 4), weight_grid=4096.0, seed0=2000),
 }
 CASES = [dict(name='decoder_ra', model='decoder_model', gop='1_GOP_2', n=3, hw=(40, 56), idx_rate=0., first=0),
          dict(name='decoder_ra_chained', model='decoder_model', gop='2_GOP_2', n=5, hw=(34, 50), idx_rate=0.5, first=4),
@@ -463,7 +465,9 @@ CASES = [dict(name='decoder_ra', model='decoder_model', gop='1_GOP_2', n=3, hw=(
          dict(name='decoder_noref_empty_y', model='decoder_model', gop='1_GOP_2', n=3, hw=(40, 56), idx_rate=0., first=0,
               variant=dict(drop_g_a_ref=True, mof_active_y=0)),
          dict(name='decoder_gain_i', model='decoder_model', gop='1_GOP_2', n=3, hw=(34, 50), idx_rate=0.5, first=0,
-              variant=dict(drop_gain_p_b=True))]
+              variant=dict(drop_gain_p_b=True)),
+         dict(name='decoder_b_gop4', model='decoder_model_b', gop='1_GOP_4', n=5, hw=(48, 64), idx_rate=0.25, first=0),
+         dict(name='decoder_b_ldp8', model='decoder_model_b', gop='LDP_8', n=9, hw=(38, 58), idx_rate=0., first=3)]
 
 
 def main():
@@ -481,7 +485,7 @@ def main():
     for mname, mp in MODELS.items():
         cases = [c for c in CASES if c['model'] == mname]
         tried = []
-        for seed in range(1000, 1100):
+        for seed in range(mp.get('seed0', 1000), mp.get('seed0', 1000) + 100):
             results = []
             for c in cases:
                 # ONE stored model for its cases; a variant case edits a fresh copy of it
