@@ -467,7 +467,9 @@ CASES = [dict(name='decoder_ra', model='decoder_model', gop='1_GOP_2', n=3, hw=(
          dict(name='decoder_gain_i', model='decoder_model', gop='1_GOP_2', n=3, hw=(34, 50), idx_rate=0.5, first=0,
               variant=dict(drop_gain_p_b=True)),
          dict(name='decoder_b_gop4', model='decoder_model_b', gop='1_GOP_4', n=5, hw=(48, 64), idx_rate=0.25, first=0),
-         dict(name='decoder_b_ldp8', model='decoder_model_b', gop='LDP_8', n=9, hw=(38, 58), idx_rate=0., first=3)]
+         dict(name='decoder_b_ldp8', model='decoder_model_b', gop='LDP_8', n=9, hw=(38, 58), idx_rate=0., first=3),
+         # mid size, hierarchical, FREE-RUNNING (no teacher sigma): 128 x 96, y 6 x 8, 9 frames through 1_GOP_8
+         dict(name='decoder_b_mid_gop8', model='decoder_model_b', gop='1_GOP_8', n=9, hw=(96, 128), idx_rate=0., first=0, noise=2.0)]
 
 
 def main():
