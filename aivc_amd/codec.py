@@ -188,6 +188,13 @@ class FrameCodec:
             pool.append(torch.cuda.Stream(priority=-1))
         return pool[:k]
 
+    def _param_stamp(self):
+        """changes whenever a parameter / buffer of the model is modified in place, replaced or moved"""
+        ts = getattr(self, '_param_list', None)
+        if ts is None:  # (walking the module tree costs 1.3 ms; the Parameter objects themselves survive .to() / load_state_dict)
+            ts = self._param_list = list(self.net.parameters()) + list(self.net.buffers())
+        return hash(tuple((t.data_ptr(), t._version) for t in ts))
+
     def _chunks(self, gop, level, unit_ids, shard=None):
         """(frame type, [(unit, frame name), ...]) batches of at most max_batch same-type frames of one
         dependency level (a level of a chained GOP mixes P and B frames); with a shard, this rank's share."""
@@ -292,9 +299,15 @@ class FrameCodec:
             # stream is still doing (in encode -> decode sequences: the last level's synthesis of the encoder), so the
             # side streams do NOT wait for it: the first levels' serial y streams decode under that work.  (Kernel-
             # ready parameters are synchronised when they are built, layers/_cache.py.)
-            if _os.environ.get('AIVC_DEC_WAIT_MAIN'):
+            # Parameters the entropy stage reads DIRECTLY (conv biases, gain vectors, the hyperprior's inputs) are not
+            # behind that cache: if any parameter was modified in place or moved since the last decode (an asynchronous
+            # bias.add_ of a calibration, load_state_dict, .to() -- on the main stream), the side streams wait for the
+            # main stream once, here.
+            stamp = self._param_stamp()
+            if _os.environ.get('AIVC_DEC_WAIT_MAIN') or stamp != getattr(self, '_dec_param_stamp', None):
                 for sd in sides:
                     sd.wait_stream(main)
+                self._dec_param_stamp = stamp
             levels = coding_levels(gop)
             lat, ready = {}, {}
             rr = [0]

@@ -19,7 +19,7 @@ int check_launch(const char *what) {
 }
 }  // namespace aivc
 
-AIVC_EXPORT int aivc_abi_version(void) { return 9; }
+AIVC_EXPORT int aivc_abi_version(void) { return AIVC_ABI_VERSION; }
 AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
 
 static int validate_conv(const aivc_conv_params *p) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/aivc_detmath.h"
 #include "../../include/aivc_hip.h"
 
@@ -12,6 +14,22 @@ namespace aivc {
 
 void set_last_error(const char *msg);
 int check_launch(const char *what);  // hipGetLastError() -> AIVC_OK / AIVC_ERR_LAUNCH
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: one process driving several GPUs through the
+// C ABI must raise it on each of them.  One bit per device ordinal (mod 64) and kernel instantiation; safe to race
+// (the worst case sets the attribute twice).
+struct LdsOptIn {
+  std::atomic<uint64_t> done{0};
+  bool raise(const void *fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+  }
+};
 
 static inline hipStream_t to_stream(aivc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -332,14 +332,8 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
 template <int NIMG>
 static int launch_images(const ImgArgs &a, hipStream_t s) {
   const size_t lds = (size_t)ic_lds_floats<NIMG>() * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_images_kernel<NIMG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return AIVC_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static LdsOptIn opt_in;  // > 64 KB of dynamic LDS needs the opt-in, on every device
+  if (lds > 64 * 1024 && !opt_in.raise(reinterpret_cast<const void *>(conv_images_kernel<NIMG>), lds)) return AIVC_ERR_LAUNCH;
   const unsigned ntiles = (unsigned)a.n * (unsigned)a.tiles_y * (unsigned)a.tiles_x;
   const unsigned grid = (ntiles + IC_TPW - 1) / IC_TPW;
   hipLaunchKernelGGL(conv_images_kernel<NIMG>, dim3(grid), dim3(256), lds, s, a);

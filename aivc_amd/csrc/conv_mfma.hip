@@ -65,7 +65,7 @@ constexpr int TAIL_N = 128;  // output channels of the fused 1x1 tail (the bottl
 // LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): LDS destination = lds_dst (wave-uniform, through M0) +
 // lane * 16, source = base (SGPR pair) + voff (per-lane byte offset).  Counts on vmcnt like a load; no VGPR result.
 __device__ __forceinline__ void glds16(const float *base, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false>
@@ -1131,13 +1131,9 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
   if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   if (lds > 64 * 1024) {
-    static bool raised = false;  // per instantiation
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return check_launch("conv_mfma lds attribute");
-      raised = true;
-    }
+    static LdsOptIn opt_in;  // per instantiation, per device
+    if (!opt_in.raise(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), lds))
+      return check_launch("conv_mfma lds attribute");
   }
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");

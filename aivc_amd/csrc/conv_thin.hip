@@ -332,17 +332,15 @@ static int launch_thin_mfma_g(const aivc_conv_params &p, hipStream_t s) {
   const size_t lds = (size_t)2 * 6 * 34 * (16 * G16 + 4) * sizeof(float);
   const int tiles_x = (p.w_in + 31) / 32, tiles_y = (p.h_in + 3) / 4;
   const int ntiles = tiles_x * tiles_y * p.n;
-  static bool attr_set = false;
-  static int n_cu = 256;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(thin_mfma_kernel<KS, CO, G16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    attr_set = true;
+  static LdsOptIn opt_in;  // per device
+  static std::atomic<int> n_cu{0};
+  if (!opt_in.raise(reinterpret_cast<const void *>(thin_mfma_kernel<KS, CO, G16>), 160 * 1024)) return check_launch("thin_mfma lds attribute");
+  if (n_cu.load(std::memory_order_relaxed) == 0) {
+    int dev = 0, cus = 0;
+    n_cu = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? cus : 256;
   }
-  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  const int cus = n_cu.load(std::memory_order_relaxed);
+  const int grid = ntiles < cus ? ntiles : cus;
   hipLaunchKernelGGL((thin_mfma_kernel<KS, CO, G16>), dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y, ntiles);
   return check_launch("thin_mfma");
 }
@@ -368,12 +366,8 @@ static int launch_thin(const aivc_conv_params &p, hipStream_t s) {
   constexpr int TH = 8;  // 8 x 16 input pixels per workgroup: <= 49 KB of LDS at 64 channels (3 groups per CU)
   const size_t lds = (size_t)(TH + 2) * 18 * (p.c_in + 4) * sizeof(float);
   const int tiles = ((p.w_in + 15) / 16) * ((p.h_in + TH - 1) / TH);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(thin_tconv_kernel<KS, CO, TH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static LdsOptIn opt_in;  // per device
+  if (!opt_in.raise(reinterpret_cast<const void *>(thin_tconv_kernel<KS, CO, TH>), 160 * 1024)) return check_launch("thin_tconv lds attribute");
   hipLaunchKernelGGL((thin_tconv_kernel<KS, CO, TH>), dim3(tiles, p.n), dim3(TH * 16), lds, s, p);
   return check_launch("thin_tconv");
 }

@@ -398,7 +398,7 @@ static_assert(DEC_WIN0 == CDF_WIN0, "window position");
 // M0 (the LDS destination base) is written in the statement that uses it (nothing else in these kernels touches M0:
 // gfx9 LDS instructions do not need it).
 __device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
 // One stream, one wavefront.  PLANE: a CDF row serves `plane` consecutive symbols (factorised prior of z), else one

@@ -89,11 +89,16 @@ def decode_video_sharded(frame_codec, blob, device=None):
     fsz = h * w + 2 * hc * wc
     owner = [None] * len(frames)  # (rank, slot) of every frame: units are dealt round-robin, known everywhere
     counts = [0] * world
-    unit = len(frames_per_unit(blob))
-    for i in range(len(frames)):
-        r = unit_owner(i // unit, world)
-        owner[i] = (r, counts[r])
-        counts[r] += 1
+    # every unit's OWN length: a container may mix coding structures (decode_video / decode_units accept that), and
+    # the padded frames of the last unit are cut from the end of `frames`
+    i = 0
+    for u, n_u in enumerate(unit_lengths(blob)):
+        for _ in range(n_u):
+            if i < len(frames):
+                owner[i] = (unit_owner(u, world), counts[unit_owner(u, world)])
+                counts[unit_owner(u, world)] += 1
+                i += 1
+    assert i == len(frames), 'the container holds %d frames, decode_video returned %d' % (i, len(frames))
     per = max(counts)
     dev = next(f['y'].device for f in frames if f is not None) if any(f is not None for f in frames) else device
     cdev = _comm_device(None, dev)
@@ -114,12 +119,11 @@ def decode_video_sharded(frame_codec, blob, device=None):
     return out
 
 
-def frames_per_unit(blob):
-    """display-order frame names of one intra-period unit of the video `blob` (all its units share a structure)"""
-    from .func_util.GOP_structure import generate_gop_struct
+def unit_lengths(blob):
+    """number of frames of every intra-period unit of the video `blob`, in order"""
     from .real_life import cat_binary_files as container
     _, _, _, gops = container.unpack_video(blob)
-    return generate_gop_struct(container.unpack_gop(gops[0])[0])
+    return [len(container.unpack_gop(g)[2]) for g in gops]
 
 
 # ---- one clip over all GPUs: unit groups x temporal-layer sharding (SURVEY.md 8e) ---------------------------

@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
                 (`parity_checked`).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -203,6 +204,16 @@ def _self_launch(n):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     os.dup2(_REAL_STDOUT, 1)  # the child job's rank 0 writes the one line there
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _structure_label(gop_name):
+    """'1_GOP_32' -> 'RA GOP32', 'LDP_8' -> 'LDP 8', '1_GOP_0' -> 'all intra' (src/func_util/GOP_structure.py:199-221)"""
+    toks = gop_name.split('_')
+    if toks[0] == 'LDP':
+        return 'LDP %s' % toks[1]
+    if toks[-1] == '0':
+        return 'all intra'
+    return 'RA GOP%s' % toks[-1] + ('' if toks[0] == '1' else ' x%s chained' % toks[0])
 
 
 def main():
@@ -435,8 +446,10 @@ def main():
             all_fl = sum(d[1] for d in mf.values())
             all_sec = sum(d[2] for d in mf.values())
             traffic, traffic_note, counters = None, None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant.json')  # counter passes on this shape at batch 16 (tools/pmc_conv.sh)
-            if os.path.exists(pmc):
+            # counter passes on this shape (tools/pmc_conv.sh; separate --pmc runs, never inside this process): the newest round's
+            pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_pmc_dominant.json')))
+            pmc = pmcs[-1] if pmcs else ''
+            if pmc:
                 pj = json.load(open(pmc))
                 if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
                     traffic = pj.get('traffic_bytes_per_launch')
@@ -478,12 +491,13 @@ def main():
         cpu = cpu_baseline(args.width, args.height, model, fc, dev)
 
     if rank == 0:
-        scaling = 'strong' if strong else 'weak'
+        # N = 1: strong and weak are the same single-process run, the label says so
+        scaling = 'single' if world == 1 else ('strong' if strong else 'weak')
         clips_done = args.steps * (1 if strong else world)
         g = shard.G if shard is not None else 1
         r_ = shard.R if shard is not None else 1
         out = {
-            'metric': 'encode+decode fps @1080p YUV420 (RA GOP32)',
+            'metric': 'encode+decode fps @%dp YUV420 (%s)' % (args.height, _structure_label(args.gop)),
             'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s',
             'n_gpus': dist.get_world_size() if use_dist else 1, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
@@ -501,8 +515,11 @@ def main():
                        'nonzero_y_maps': {'mofnet': active_y[0], 'codecnet': active_y[1], 'of': widths['c_y']},
                        'parallelism': ('unit-groups x%d, level-sharded x%d' % (g, r_)) if sharded else ('single GPU' if world == 1 else 'replicas x%d' % world)},
             'coded_frames_per_s': round(clips_done * coded / elapsed, 4),
-            'encode_fps_rank0': round(args.steps * args.frames / stats['enc_s'], 3),
-            'decode_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),
+            # main-stream time between events recorded after each phase was ISSUED: the decoder's entropy stage starts
+            # on side streams under the encoder's last synthesis, so the two halves overlap (not comparable with the
+            # host-synchronised encode_fps_rank0 / decode_fps_rank0 of rounds 1-2; `value` is wall clock and unaffected)
+            'encode_main_stream_fps_rank0': round(args.steps * args.frames / stats['enc_s'], 3),
+            'decode_main_stream_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),
             'bytes_per_frame': round(stats['bytes'] / (args.steps * coded), 1),
             'closed_loop_ok': bool(closed_loop), 'bytes_equal_single_rank': bytes_equal,
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,

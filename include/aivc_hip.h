@@ -61,8 +61,9 @@ enum {
 /* ------------------------------------------------------------------------------------------
  * Library identity
  * ---------------------------------------------------------------------------------------- */
-/* ABI version, bumped whenever a struct or signature changes. */
-int aivc_abi_version(void); /* currently 9 */
+/* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
+#define AIVC_ABI_VERSION 9
+int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
 

@@ -277,6 +277,25 @@ def main():
         finally:
             os.chdir(cwd)
     save('container', **cont)
+
+    # ---- a1-a5 at the hot-path widths (64 / 128 channels): parameters and inputs are seeded, not stored --------
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import wide_cases
+    from layers.misc import custom_conv_layers as ref_ccl, attention as ref_att
+    for name, build, kw, in_shape, seed, variants, force_tiles in wide_cases.CASES:
+        if build == 'first_layer':
+            m = CustomConvLayer(k_size=5, in_ft=3 * kw['n_img'], out_ft=64, non_linearity='gdn', conv_stride=2).eval()
+            planes, sha = wide_cases.load_seeded(m, name)
+            with torch.no_grad():
+                dics = [{k: torch.from_numpy(p[k]).float().unsqueeze(0) / 255. for k in 'yuv'} for p in planes]
+                y = m(torch.cat([InputLayer()(d) for d in dics], dim=1))
+        else:
+            cls = getattr(ref_att, build, None) or getattr(ref_ccl, build)
+            m = cls(**kw).eval()
+            x, sha = wide_cases.load_seeded(m, name)
+            with torch.no_grad():
+                y = m(torch.from_numpy(x))
+        save('wide_' + name, y=y, sha256=np.array(sha), cfg=np.array(repr(dict(build=build, kw=kw, in_shape=in_shape, seed=seed))))
     print('done')
 
 

@@ -4,7 +4,7 @@
 out=$1
 echo "# python bench.py --no-cpu-baseline --no-roofline <flags>, one MI355X, same box" > $out
 run() {
-  line=$(timeout 400 python bench.py --no-cpu-baseline --no-roofline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','coded_frames_per_s','ms_per_step','encode_fps_rank0','decode_fps_rank0','closed_loop_ok','bytes_per_frame')})")
+  line=$(timeout 400 python bench.py --no-cpu-baseline --no-roofline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('value','coded_frames_per_s','ms_per_step','encode_main_stream_fps_rank0','decode_main_stream_fps_rank0','closed_loop_ok','bytes_per_frame')})")
   echo "$* $line" >> $out
 }
 run                                                       # configs[3] on one GPU (the headline workload)

@@ -8,7 +8,7 @@ for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
         continue
     d = json.loads(line)
     print('value %.3f %s | enc %.2f dec %.2f fps | ms/step %.1f | closed_loop %s | bytes/frame %.0f' % (
-        d['value'], d['unit'], d.get('encode_fps_rank0', 0), d.get('decode_fps_rank0', 0), d['ms_per_step'],
+        d['value'], d['unit'], d.get('encode_main_stream_fps_rank0', d.get('encode_fps_rank0', 0)), d.get('decode_main_stream_fps_rank0', d.get('decode_fps_rank0', 0)), d['ms_per_step'],
         d.get('closed_loop_ok'), d.get('bytes_per_frame', 0)))
     r = d.get('roofline')
     if r:
