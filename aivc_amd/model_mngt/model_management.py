@@ -20,12 +20,24 @@ def attach_arithmetic_coders(model, device=None):
 
 
 def load_model(prefix='', on_cpu=False):
-    """torch.load of a full-module pickle './<prefix>model.pt' (reference pickles resolve their
-    classes here through aivc_amd.install_aliases())."""
+    """torch.load of a full-module pickle './<prefix>model.pt' (src/model_mngt/model_management.py:341-361).
+    Classes are resolved by the dotted path the pickle names (the reference's module names are aliases of this
+    package, aivc_amd.install_aliases()) and, where that path does not exist here -- the `models` package is missing
+    from the reference snapshot, its real module layout is unknown -- by CLASS NAME over this package's classes
+    (pickle_compat.py).  Every name that resolves neither way is reported before the load starts."""
     import aivc_amd
+    from . import pickle_compat
     aivc_amd.install_aliases()
+    path = './' + prefix + 'model.pt'
+    missing = pickle_compat.unresolved(path)
+    if missing:
+        raise ImportError('%s names classes this build does not define: %s -- list what the file asks for with '
+                          '`python tools/inspect_pickle.py %s`' % (path, ', '.join('%s.%s' % mn for mn in missing), path))
     map_loc = torch.device('cpu') if on_cpu else None
-    model = torch.load('./' + prefix + 'model.pt', map_location=map_loc, weights_only=False)
+    by_name = []
+    model = torch.load(path, map_location=map_loc, weights_only=False, pickle_module=pickle_compat.resolver(by_name))
+    for mod, name, target in by_name:
+        print_log_msg('INFO', 'load_model', 'class resolved by name', '%s.%s -> %s' % (mod, name, target))
     return attach_arithmetic_coders(model, map_loc)
 
 

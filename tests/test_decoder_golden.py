@@ -23,7 +23,10 @@ from oracle import spec as ospec
 # LDP_8 from frame 3 on an odd-sized frame, and 1_GOP_8 at 128 x 96 decoded FREE-RUNNING (the second seed tried: the first
 # desynchronised, which the fixture's search log records)
 CASES = ['decoder_ra', 'decoder_ra_chained', 'decoder_ldp_odd', 'decoder_big_gop8', 'decoder_noref_empty_y',
-         'decoder_gain_i', 'decoder_b_gop4', 'decoder_b_ldp8', 'decoder_b_mid_gop8']
+         'decoder_gain_i', 'decoder_b_gop4', 'decoder_b_ldp8', 'decoder_b_mid_gop8', 'decoder_mid_gop8']
+# decoder_mid_gop8: MID widths (n2 32, n 64, c_y = c_short = c_z = 32, n_h 64: c_in % 32 == 0 on every layer behind the
+# image layers, i.e. the LDS-DMA K loop, fused-GDN / fused-tail tiles and the thin MFMA kernel carry the decode), 1_GOP_8 at
+# 128 x 96, 20 + 6 coded maps, writer's sigma; its 3.2 M parameters are seeded (decoder_variants.seeded_init), not stored
 NAMES = ('mofnet', 'codecnet')
 
 
@@ -41,9 +44,14 @@ def _model(golden, case='decoder_ra', device=None):
     g = golden(cm.get('model', 'decoder_model'))
     m = _meta(g)
     model = FullNet({'widths': m['widths'], 'nb_rates': m['nb_rates']})
-    sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
-    missing, unexpected = model.load_state_dict(sd, strict=True)
-    assert not missing and not unexpected
+    if m.get('seeded'):
+        from decoder_variants import seeded_init
+        assert seeded_init(model, m['seed'], m['active_y'], m['weight_grid']) == m['sha256'], \
+            'the seeded draw no longer reproduces the parameters the reference ran on'
+    else:
+        sd = {k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith('sd.')}
+        missing, unexpected = model.load_state_dict(sd, strict=True)
+        assert not missing and not unexpected
     model = apply_variant(model, cm.get('variant', {})).eval()
     if device is not None:
         model = attach_arithmetic_coders(model.to(device))
@@ -164,6 +172,36 @@ def test_oracle_decode_equals_reference_decoder(case, oracle, golden):
             assert diff.max() <= 1, (case, k)  # north_star: within 1 LSB of the reference
             n_off += int((diff != 0).sum())
     assert n_off <= _pixel_budget(m, want)
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c in ('decoder_big_gop8', 'decoder_mid_gop8')])
+def test_free_running_statistic_of_teacher_sigma_cases(case, oracle, golden):
+    """The writer's-sigma cases, decoded WITHOUT the writer's sigma: the outcome (desynchronised: how many pixels
+    differ, by how much) was recorded by the generator in the model fixture's search log; the deterministic oracle must
+    reproduce exactly that record, so a change of the sigma path that makes free-running decodes better or worse
+    shows up here instead of hiding behind the teacher"""
+    g = golden(case)
+    m = _meta(g)
+    assert m['teacher_sigma']
+    log = ast.literal_eval(str(golden(m['model'])['search_log']))
+    rec = [st for seed, name, ok, st in log if name == case and ok][-1]['free_running']
+    spec = ospec.export_model(_model(golden, case))
+    try:
+        dec = ocodec.decode_video(spec, np.asarray(g['video_file']).tobytes(), None)
+    except Exception as e:  # a desynchronised stream can run the coder out of its alphabet
+        assert 'error' in rec, (rec, repr(e))
+        return
+    want = _frames(g, m, 'dec')
+    worst = n_diff = n_equal = 0
+    for d, w in zip(dec, want):
+        same = True
+        for k in 'yuv':
+            diff = np.abs(d[k].astype(np.int32) - w[k].astype(np.int32))
+            worst = max(worst, int(diff.max()))
+            n_diff += int((diff != 0).sum())
+            same &= not diff.any()
+        n_equal += same
+    assert {'max_abs_lsb': worst, 'n_pixels_differ': n_diff, 'frames_equal': n_equal} == rec
 
 
 @pytest.mark.parametrize('case', CASES)

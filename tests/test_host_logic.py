@@ -4,6 +4,7 @@ import ctypes
 import io
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -206,3 +207,72 @@ def test_encode_batch_hands_sections_over_before_the_synthesis():
     src = inspect.getsource(codec.FrameCodec.encode_batch)
     assert src.index('on_sections(sections)') < src.index('self.cod.synthesise(')
     assert 'on_sections=' in inspect.getsource(codec.FrameCodec.encode_units)
+
+
+def _save_under_foreign_module_names(model, rename):
+    """torch.save(model) as a pickle whose classes live at other dotted paths: rename(cls) -> module name"""
+    import types
+    classes = {type(m) for m in model.modules() if type(m).__module__.startswith('aivc_amd.')}
+    saved = {c: c.__module__ for c in classes}
+    fake = {}
+    try:
+        for c in classes:
+            new = rename(c)
+            if new not in sys.modules:
+                fake[new] = sys.modules[new] = types.ModuleType(new)
+            if new in fake:
+                setattr(fake[new], c.__name__, c)
+            c.__module__ = new
+        buf = io.BytesIO()
+        torch.save(model, buf)
+    finally:
+        for c, m in saved.items():
+            c.__module__ = m
+        for k in fake:
+            del sys.modules[k]
+    return buf.getvalue()
+
+
+def test_load_model_resolves_unknown_module_paths_by_class_name(tmp_path, monkeypatch):
+    """The dotted paths of the pickled `models.*` classes are unknown (the package is missing from the reference
+    snapshot): a file that puts FullNet at models.net and the conditional coders at models.cond.sub
+    loads through load_model's class-name fallback (src/model_mngt/model_management.py:341-361 is a plain torch.load),
+    the inspector lists what it asks for without unpickling, and an unknown class is reported by name up front."""
+    import aivc_amd
+    from aivc_amd import synth
+    from aivc_amd.model_mngt import model_management, pickle_compat
+    from aivc_amd.models import arch
+    aivc_amd.install_aliases()
+    model = synth.make_model(arch.TINY_WIDTHS, seed=5)
+    for net in (model.codec_net.codec_net, model.mode_net.mode_net):
+        net.ac = None
+
+    def rename(c):
+        ref = c.__module__[len('aivc_amd.'):]
+        if not ref.startswith('models.'):
+            return ref  # layer classes: the reference's own paths
+        return 'models.net' if c.__name__ == 'FullNet' else 'models.cond.sub'
+    raw = _save_under_foreign_module_names(model, rename)
+    names = pickle_compat.pickle_globals(raw)
+    assert ('models.net', 'FullNet') in names and ('models.cond.sub', 'ConditionalNet') in names
+    assert ('layers.misc.custom_conv_layers', 'CustomConvLayer') in names
+    assert pickle_compat.unresolved(raw) == []
+    (tmp_path / '0_model.pt').write_bytes(raw)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(model_management, 'attach_arithmetic_coders', lambda m, d=None: m)  # (the coder's tables are GPU work)
+    loaded = model_management.load_model(prefix='0_', on_cpu=True)
+    assert type(loaded).__module__ == 'aivc_amd.models.full_net'
+    sd_a, sd_b = model.state_dict(), loaded.state_dict()
+    assert sd_a.keys() == sd_b.keys() and all(torch.equal(sd_a[k], sd_b[k]) for k in sd_a)
+    # the command-line inspector over the same file
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'inspect_pickle.py'), '0_model.pt'],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'models.net.FullNet' in out.stdout and 'by NAME -> aivc_amd.models.full_net.FullNet' in out.stdout
+    # a class this build does not define: named in the error, before anything is unpickled
+    foo = type('FooBNet', (type(model),), {'__module__': 'aivc_amd.models.full_net'})
+    model.__class__ = foo
+    raw2 = _save_under_foreign_module_names(model, lambda c: 'models.net' if c is foo else rename(c))
+    (tmp_path / '1_model.pt').write_bytes(raw2)
+    with pytest.raises(ImportError, match='models.net.FooBNet'):
+        model_management.load_model(prefix='1_', on_cpu=True)

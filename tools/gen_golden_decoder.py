@@ -62,7 +62,7 @@ from oracle import codec as ocodec  # noqa: E402
 from oracle import spec as ospec  # noqa: E402
 from aivc_amd import abi  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from decoder_variants import apply_variant  # noqa: E402
+from decoder_variants import apply_variant, seeded_init  # noqa: E402
 
 TORCHAC_LOG = []  # (kind, cdf_u16 [N,514], sym [N]) of every call the reference makes
 TORCHAC_KIND = ['stub: published normalisation + the oracle coder']  # which torchac the reference ran on
@@ -132,9 +132,12 @@ def install_stubs():
 
 WIDTHS = {'n2': 8, 'n': 16, 'c_y': 8, 'c_short': 8, 'c_z': 4, 'n_h': 8}  # == aivc_amd arch.TINY_WIDTHS
 WIDTHS_BIG = {'n2': 8, 'n': 16, 'c_y': 16, 'c_short': 8, 'c_z': 8, 'n_h': 16}
+# every conv past the image layers has c_in % 32 == 0: the LDS-DMA K loop, the fused-GDN / fused-tail tiles and the thin
+# MFMA kernel carry the whole decode (3.2 M parameters: seeded, not stored -- tests/decoder_variants.py seeded_init)
+WIDTHS_MID = {'n2': 32, 'n': 64, 'c_y': 32, 'c_short': 32, 'c_z': 32, 'n_h': 64}
 
 
-def build_reference_model(seed, active_y, wd=None, weight_grid=None):
+def build_reference_model(seed, active_y, wd=None, weight_grid=None, seeded=False):
     """FullNet look-alike made of the reference's layer classes (module / attribute names of
     aivc_amd/models/{full_net,mode_net,codec_net,conditional_net}.py)."""
     from torch.nn import Module, Sequential
@@ -212,6 +215,9 @@ def build_reference_model(seed, active_y, wd=None, weight_grid=None):
 
     torch.manual_seed(seed)
     model = FullNet()
+    if seeded:  # parameters from numpy's frozen generator: the fixture stores the seed + a digest, not the tensors
+        model.seeded_sha256 = seeded_init(model, seed, active_y, weight_grid)
+        return attach_coders(model.eval())
     gen = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -454,6 +460,8 @@ MODELS = {
     'decoder_model_big': dict(widths=WIDTHS_BIG, active_y=(5, 16), weight_grid=4096.0),
     # a second draw of the small model (other seed range, other number of coded maps) for two more coding structures
     'decoder_model_b': dict(widths=WIDTHS, active_y=(3, 4), weight_grid=4096.0, seed0=2000),
+    # mid widths (c_in % 32 == 0 on every layer behind the image layers), seeded parameters
+    'decoder_model_mid': dict(widths=WIDTHS_MID, active_y=(6, 20), weight_grid=4096.0, seed0=3000, seeded=True),
 }
 CASES = [dict(name='decoder_ra', model='decoder_model', gop='1_GOP_2', n=3, hw=(40, 56), idx_rate=0., first=0),
          dict(name='decoder_ra_chained', model='decoder_model', gop='2_GOP_2', n=5, hw=(34, 50), idx_rate=0.5, first=4),
@@ -469,7 +477,10 @@ CASES = [dict(name='decoder_ra', model='decoder_model', gop='1_GOP_2', n=3, hw=(
          dict(name='decoder_b_gop4', model='decoder_model_b', gop='1_GOP_4', n=5, hw=(48, 64), idx_rate=0.25, first=0),
          dict(name='decoder_b_ldp8', model='decoder_model_b', gop='LDP_8', n=9, hw=(38, 58), idx_rate=0., first=3),
          # mid size, hierarchical, FREE-RUNNING (no teacher sigma): 128 x 96, y 6 x 8, 9 frames through 1_GOP_8
-         dict(name='decoder_b_mid_gop8', model='decoder_model_b', gop='1_GOP_8', n=9, hw=(96, 128), idx_rate=0., first=0, noise=2.0)]
+         dict(name='decoder_b_mid_gop8', model='decoder_model_b', gop='1_GOP_8', n=9, hw=(96, 128), idx_rate=0., first=0, noise=2.0),
+         # the mid-width model through 1_GOP_8 at 128 x 96 (y 6 x 8, z 2 x 2; 20 + 6 coded maps); writer's sigma allowed
+         dict(name='decoder_mid_gop8', model='decoder_model_mid', gop='1_GOP_8', n=9, hw=(96, 128), idx_rate=0., first=0,
+              noise=2.0, teacher_sigma=True, keep_raw=False)]
 
 
 def main():
@@ -491,7 +502,7 @@ def main():
             results = []
             for c in cases:
                 # ONE stored model for its cases; a variant case edits a fresh copy of it
-                model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'))
+                model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'), mp.get('seeded', False))
                 if c.get('variant'):
                     model = attach_coders(apply_variant(model, c['variant']))
                 frames = synthetic_video(c['hw'][1], c['hw'][0], c['n'], seed=seed, noise=c.get('noise', 4.0))
@@ -515,10 +526,13 @@ def main():
                 break
         else:
             raise SystemExit('no seed passed for ' + mname)
-        model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'))
+        model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'), mp.get('seeded', False))
         sd = {'sd.' + k: v.detach().numpy() for k, v in model.state_dict().items()}
         path = os.path.join(OUT, mname + '.npz')
         meta = dict(widths=mp['widths'], nb_rates=2, seed=seed, active_y=mp['active_y'], torchac=TORCHAC_KIND[0])
+        if mp.get('seeded'):
+            meta.update(seeded=True, weight_grid=mp.get('weight_grid'), sha256=model.seeded_sha256)
+            sd = {}
         np.savez_compressed(path, meta=np.array(repr(meta)), search_log=np.array(repr(tried)), **sd)
         print('%-28s %7.1f kB' % (mname + '.npz', os.path.getsize(path) / 1e3))
         for c, frames, fix, data_dim, log in results:
@@ -526,7 +540,7 @@ def main():
                 for k in 'yuv':
                     if c.get('keep_raw', True):
                         fix['raw_%d_%s' % (c['first'] + i, k)] = f[k]
-            model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'))
+            model = build_reference_model(seed, mp['active_y'], mp['widths'], mp.get('weight_grid'), mp.get('seeded', False))
             if c.get('variant'):
                 model = attach_coders(apply_variant(model, c['variant']))
             meta = dict(gop=c['gop'], idx_rate=c['idx_rate'], first=c['first'], n=c['n'], model=mname,
