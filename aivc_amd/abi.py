@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -105,8 +105,8 @@ PROTOTYPES = {
     'aivc_laplace_bounds': [_f, _f, _sz, _i32, _P(MapList), _f],
     'aivc_table_bounds': [_f, _f, _sz, _i32, _f],
     'aivc_range_encode': [_f, _P(RcBatch), _f, _f],
-    'aivc_range_decode': [_f, _f, _P(RcBatch), _f],
-    'aivc_range_decode_windows': [_f, _f, _f, _P(RcBatch), _f],
+    'aivc_range_decode': [_f, _f, _P(RcBatch), _f, _f],
+    'aivc_range_decode_windows': [_f, _f, _f, _P(RcBatch), _f, _f],
     'aivc_scatter_symbols': [_f, _sz, _i32, _P(MapList), _f],
 }
 

@@ -33,8 +33,10 @@ def resolve_device(cpu_flag):
     return dev
 
 
-def get_model(name, device, models_dir='../models'):
+def get_model(name, device, models_dir=None):
     import aivc_amd
+    # the reference runs from src/ and reads ../models/<name>/0_model.pt (src/encode.py:101-103); AIVC_MODELS_DIR moves it
+    models_dir = models_dir or os.environ.get('AIVC_MODELS_DIR', '../models')
     from aivc_amd import synth
     from aivc_amd.model_mngt.model_management import load_model
     path = os.path.join(models_dir, name)

@@ -188,6 +188,20 @@ class FrameCodec:
             pool.append(torch.cuda.Stream(priority=-1))
         return pool[:k]
 
+    def stream_errors(self):
+        """Sections decoded since the last call whose range decoder did not end where their payload ends (see
+        ArithmeticCoder.stream_errors), plus failed md5 sections under flag_md5sum -- [(network, what, ...)].
+        Waits for the decodes concerned; call it after the frames have been fetched."""
+        out = []
+        for name, net in (('mofnet', self.mof), ('codecnet', self.cod)):
+            ac = getattr(net, 'ac', None)
+            if ac is None:
+                continue
+            out += [(name,) + e for e in ac.stream_errors()]
+            out += [(name, what + ' md5', i, 0, 0) for what, i in ac.md5_errors]
+            ac.md5_errors = []
+        return out
+
     def _param_stamp(self):
         """changes whenever a parameter / buffer of the model is modified in place, replaced or moved"""
         ts = getattr(self, '_param_list', None)

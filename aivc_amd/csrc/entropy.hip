@@ -410,7 +410,7 @@ __device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, 
 // WINDOWED: `rows` holds only the 64-entry window of every position (laplace_cdf_windows_kernel) and `sigma_pos` its
 // sigma: the slow path evaluates the entries it needs itself.
 template <bool PLANE, bool WINDOWED = false>
-__device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes, const uint16_t *__restrict__ rows,
+__device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ bytes, const uint16_t *__restrict__ rows,
                                               const aivc_rc_stream &st, uint16_t *__restrict__ sym, uint32_t *ring,
                                               const int lane, const float *__restrict__ sigma_pos = nullptr) {
   static_assert(!(PLANE && WINDOWED), "windows are per-position Laplace rows");
@@ -548,31 +548,42 @@ __device__ __forceinline__ void decode_stream(const uint8_t *__restrict__ bytes,
     }
     if ((uint32_t)lane < cnt) sym[st.out_off + first + lane] = (uint16_t)mysym;
   }
+  // bits shifted in by renormalisation over the whole stream (the window was primed with 64 at word index 2)
+  return bw.wi * 32u - bw.avail;
 }
 
 __global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
                                                           const uint16_t *__restrict__ rows, aivc_rc_batch batch,
-                                                          uint16_t *__restrict__ sym) {
+                                                          uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
   __shared__ uint32_t ring[DEC_D * 64];  // the DMA writes one dword per lane (a ushort load lands zero-extended at lane * 4)
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
-  if (st.n_sym == 0) return;
+  if (st.n_sym == 0) {
+    if (consumed && lane == 0) consumed[blockIdx.x] = 0;
+    return;
+  }
   __builtin_amdgcn_s_setprio(3);  // latency-critical serial wave (see range_encode_kernel)
-  if (st.plane) decode_stream<true>(bytes, rows, st, sym, ring, lane);
-  else decode_stream<false>(bytes, rows, st, sym, ring, lane);
+  uint32_t bits;
+  if (st.plane) bits = decode_stream<true>(bytes, rows, st, sym, ring, lane);
+  else bits = decode_stream<false>(bytes, rows, st, sym, ring, lane);
+  if (consumed && lane == 0) consumed[blockIdx.x] = bits;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
 __global__ __launch_bounds__(64) void range_decode_windows_kernel(const uint8_t *__restrict__ bytes,
                                                                   const uint16_t *__restrict__ win,
                                                                   const float *__restrict__ sigma_pos, aivc_rc_batch batch,
-                                                                  uint16_t *__restrict__ sym) {
+                                                                  uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
   __shared__ uint32_t ring[DEC_D * 64];
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x;
-  if (st.n_sym == 0) return;
+  if (st.n_sym == 0) {
+    if (consumed && lane == 0) consumed[blockIdx.x] = 0;
+    return;
+  }
   __builtin_amdgcn_s_setprio(3);
-  decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_pos);
+  const uint32_t bits = decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_pos);
+  if (consumed && lane == 0) consumed[blockIdx.x] = bits;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -688,7 +699,8 @@ AIVC_EXPORT int aivc_laplace_cdf_windows(const float *sigma, size_t npix, int32_
 }
 
 AIVC_EXPORT int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *win, const float *sigma_pos,
-                                          const aivc_rc_batch *batch, uint16_t *sym, aivc_stream_t stream) {
+                                          const aivc_rc_batch *batch, uint16_t *sym, uint32_t *consumed_bits,
+                                          aivc_stream_t stream) {
   if (!bytes || !win || !sigma_pos || !sym) return AIVC_ERR_ARG;
   if (int rc = check_batch(batch)) return rc;
   if (batch->n_streams == 0) return AIVC_OK;
@@ -697,12 +709,12 @@ AIVC_EXPORT int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *
     if (((uint64_t)batch->s[i].n_sym + 1) * (uint64_t)(CDF_WIN * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(range_decode_windows_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, win,
-                     sigma_pos, *batch, sym);
+                     sigma_pos, *batch, sym, consumed_bits);
   return check_launch("range_decode_windows");
 }
 
 AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, const aivc_rc_batch *batch,
-                                  uint16_t *sym, aivc_stream_t stream) {
+                                  uint16_t *sym, uint32_t *consumed_bits, aivc_stream_t stream) {
   if (!bytes || !rows || !sym) return AIVC_ERR_ARG;
   if (int rc = check_batch(batch)) return rc;
   if (batch->n_streams == 0) return AIVC_OK;
@@ -713,6 +725,6 @@ AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, co
     if ((n_rows + 1) * (uint64_t)(AIVC_CDF_ROW * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(range_decode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, rows,
-                     *batch, sym);
+                     *batch, sym, consumed_bits);
   return check_launch("range_decode");
 }

@@ -22,3 +22,5 @@ def main(argv=None):
 
 if __name__ == '__main__':
     main()
+    from aivc_amd.real_life.decode import STREAM_ERRORS
+    raise SystemExit(3 if STREAM_ERRORS else 0)  # the frames were written, but the stream did not decode cleanly

@@ -608,13 +608,14 @@ def range_encode(bounds_list, streams=None):
     return out, lens, out_offs
 
 
-def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None):
+def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None, want_bits=False):
     """Decode len(payloads) independent streams concurrently (one wavefront each, <= 64 per launch).
     rows: ONE int16 CUDA tensor [n_rows, CDF_ROW] holding every stream's CDF rows; stream i starts at
     row row_offs[i] and uses one row per symbol (planes[i] == 0) or row i // planes[i] (pmf tables).
     With sigma_pos (float32 [n_rows]) `rows` holds the 64-entry windows of laplace_cdf_windows instead
     ([n_rows, CDF_WIN]; planes must be 0).
-    Returns a list of int16 CUDA tensors (uint16 payload: symbols 0..512)."""
+    Returns a list of int16 CUDA tensors (uint16 payload: symbols 0..512); with want_bits also an int32 CUDA tensor [n]
+    of the bits each stream consumed (include/aivc_hip.h: len(payload) == (bits + 2 + 7) // 8 for an intact stream)."""
     n = len(payloads)
     dev = rows.device
     offs, total = [], 0
@@ -633,7 +634,9 @@ def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None):
     sym_total = int(sum(n_syms))
     sym = torch.empty(max(sym_total, 1), dtype=torch.int16, device=dev)
     outs, so = [], 0
+    bits = torch.empty(n, dtype=torch.int32, device=dev) if want_bits else None
     for start in range(0, n, abi.RC_MAX_STREAMS):
+        bp = None if bits is None else bits.data_ptr() + 4 * start
         batch = abi.RcBatch()
         cnt = 0
         for i in range(start, min(n, start + abi.RC_MAX_STREAMS)):
@@ -645,10 +648,10 @@ def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None):
             cnt += 1
         batch.n_streams = cnt
         if sigma_pos is None:
-            call('aivc_range_decode', _p(dbytes), _p(rows), C.byref(batch), _p(sym), _stream())
+            call('aivc_range_decode', _p(dbytes), _p(rows), C.byref(batch), _p(sym), bp, _stream())
         else:
-            call('aivc_range_decode_windows', _p(dbytes), _p(rows), _p(sigma_pos), C.byref(batch), _p(sym), _stream())
-    return outs
+            call('aivc_range_decode_windows', _p(dbytes), _p(rows), _p(sigma_pos), C.byref(batch), _p(sym), bp, _stream())
+    return (outs, bits) if want_bits else outs
 
 
 def scatter_symbols(sym, npix, c, maps):

@@ -224,6 +224,10 @@ class ArithmeticCoder():
         # debug: prepend / verify the reference's feature-wise md5 on every section (bitstream.py:26-49)
         self.flag_md5sum = get_value('flag_md5sum', param, default)
         self.md5_errors = []
+        # desynchronisation detector: (what, bits consumed per stream on their way to the host, event, payload lengths)
+        # of every range-decode launch since the last stream_errors() call
+        self.flag_check_lengths = True
+        self._length_checks = []
         self.AC_MAX_VAL = get_value('AC_MAX_VAL', param, default)
         if self.AC_MAX_VAL != abi.AC_MAX_VAL:
             raise NotImplementedError('the kernels are built for AC_MAX_VAL = %d' % abi.AC_MAX_VAL)
@@ -271,12 +275,42 @@ class ArithmeticCoder():
                 print('\t%s frame %d of the batch' % (what, i))
                 print('-' * 80)
 
+    def _watch(self, what, bits, lens):
+        """queue the check `len(payload) == (bits + 2 + 7) // 8` of a decode launch (include/aivc_hip.h,
+        aivc_range_decode): an async copy of 4 bytes per stream + an event on the decoding stream, no host wait"""
+        if not self.flag_check_lengths or bits is None:
+            return
+        if len(self._length_checks) >= 65536:  # nobody is collecting (a long-running service): keep the newest
+            del self._length_checks[:32768]
+        host = _pinned(bits.numel(), torch.int32)
+        host.copy_(bits, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._length_checks.append((what, host, ev, list(lens), bits))
+
+    def stream_errors(self):
+        """-> [(what, index of the stream in its launch, payload bytes, bytes its decode accounts for)] of every range
+        decode since the last call whose bit count contradicts its payload length, i.e. that was not decoded with the
+        CDFs it was written with (another implementation's sigma, a damaged file, a wrong model): the symbols of such
+        a stream are garbage from the first differing bound on, and neither torchac nor the format says so.  Waits
+        for the decodes concerned."""
+        bad = []
+        for what, host, ev, lens, _ in self._length_checks:
+            ev.synchronize()
+            for i, (b, ln) in enumerate(zip(host.numpy().tolist(), lens)):
+                if (int(b) + 2 + 7) // 8 != ln:
+                    bad.append((what, i, ln, (int(b) + 2 + 7) // 8))
+            _unpin(host)
+        self._length_checks = []
+        return bad
+
     def decode_z(self, payloads, h, w, c, device):
         """list of n payloads -> q_z int16 NHWC [n,h,w,c] (pmf mode, all channels); the n streams
         are decoded concurrently."""
         payloads, sums = self._strip_md5(payloads)
         n, npix = len(payloads), h * w
-        syms = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n)
+        syms, bits = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n, want_bits=True)
+        self._watch('z latent', bits, [len(p) for p in payloads])
         maps = list(range(c))
         q = torch.stack([ops.scatter_symbols(s, npix, c, maps).view(h, w, c) for s in syms])
         self._check_md5(q, sums, 'z latent')
@@ -300,9 +334,10 @@ class ArithmeticCoder():
             win, sig = _rows_workspace(total, sigma.device)
             for i in live:
                 ops.laplace_cdf_windows(sigma[i:i + 1], maps[i], out=(win, sig), row_off=row_offs[i])
-            dec = ops.range_decode([payloads[i][1 + len(maps[i]):] for i in live], win,
-                                   [row_offs[i] for i in live], [len(maps[i]) * npix for i in live], [0] * len(live),
-                                   sigma_pos=sig)
+            coded = [payloads[i][1 + len(maps[i]):] for i in live]
+            dec, bits = ops.range_decode(coded, win, [row_offs[i] for i in live], [len(maps[i]) * npix for i in live],
+                                         [0] * len(live), sigma_pos=sig, want_bits=True)
+            self._watch('y latent', bits, [len(p) for p in coded])
             syms = dict(zip(live, dec))
         q = torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
         self._check_md5(q, sums, 'y latent')

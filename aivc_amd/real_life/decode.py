@@ -102,14 +102,16 @@ def decode_one_video(param):
     from .. import parallel
     from . import cat_binary_files as container
     rank, world = parallel.rank_world()
+    fc = FrameCodec(decoder.full_net)
     with torch.no_grad():
         if world > 1:  # one process per GPU: every rank decodes its intra-period units, rank 0 collects the planes
             _, first, last, _ = container.unpack_video(blob)
-            frames = parallel.decode_video_sharded(FrameCodec(decoder.full_net), blob, dev)
+            frames = parallel.decode_video_sharded(fc, blob, dev)
         else:
-            frames, data_dim, first, last = FrameCodec(decoder.full_net).decode_video(blob, dev)
+            frames, data_dim, first, last = fc.decode_video(blob, dev)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    report_stream_errors(fc, path)  # (every rank reports the sections IT decoded)
     if rank != 0:
         dist_barrier_after_write(world)
         return None
@@ -124,6 +126,29 @@ def decode_one_video(param):
     if get_value('flag_bitstream_debug', param, default):
         check_debug_md5(frames, first, debug_dir(path))
     return frames
+
+
+STREAM_ERRORS = []  # what the last decode_one_video found (the CLI's exit status)
+
+
+def report_stream_errors(frame_codec, path=''):
+    """A bitstream written on another implementation of the transforms (the reference on torch: its sigma differs
+    from this build's in the last bits), a damaged file or the wrong model decodes WITHOUT any error from the range
+    coder -- it just yields other symbols from the first differing CDF bound on.  Two detectors say so: the md5
+    sections of flag_md5sum (src/real_life/bitstream.py:488-499) and, always on, the decoder's bit count against the
+    section length.  Printed in the reference's style, not raised; the CLI exits non-zero."""
+    errs = frame_codec.stream_errors()
+    del STREAM_ERRORS[:]
+    STREAM_ERRORS.extend(errs)
+    if errs:
+        print('-' * 80)
+        print('[WARN] %d section(s) of %s did not decode to where their payload ends: the stream was NOT written with the '
+              'CDFs this decoder builds (other implementation of the transforms / other model / damaged file); the '
+              'frames from the first such section on are unreliable' % (len(errs), path or 'the bitstream'))
+        for net, what, i, have, need in errs[:8]:
+            print('\t%s %s, stream %d of its launch: payload %d bytes, decode accounts for %d' % (net, what, i, have, need))
+        print('-' * 80)
+    return errs
 
 
 def dist_barrier_after_write(world):

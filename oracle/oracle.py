@@ -379,7 +379,7 @@ def laplace_cdf_windows(sigma, maps):
     return win, sp
 
 
-def range_decode_windows(payload, win, sigma_pos, n_sym):
+def range_decode_windows(payload, win, sigma_pos, n_sym, want_bits=False):
     win = np.ascontiguousarray(win, np.uint16)
     sigma_pos = _f32(sigma_pos)
     buf = np.frombuffer(payload, np.uint8)
@@ -390,9 +390,10 @@ def range_decode_windows(payload, win, sigma_pos, n_sym):
     b.n_streams = 1
     s = b.s[0]
     s.in_off, s.out_off, s.row_off, s.n_sym, s.in_len, s.plane = 0, 0, 0, n_sym, len(buf), 0
-    _chk(lib()['aivc_range_decode_windows'](_p(padded), _p(win), _p(sigma_pos), C.byref(b), _p(sym), None),
+    bits = np.zeros(1, np.uint32)
+    _chk(lib()['aivc_range_decode_windows'](_p(padded), _p(win), _p(sigma_pos), C.byref(b), _p(sym), _p(bits), None),
          'aivc_range_decode_windows')
-    return sym
+    return (sym, int(bits[0])) if want_bits else sym
 
 
 def laplace_bounds(sigma, q, maps):
@@ -433,8 +434,9 @@ def range_encode(bounds):
     return out[:out_len[0]].tobytes()
 
 
-def range_decode(payload, rows, n_sym, plane=0):
-    """rows: [n_rows][CDF_ROW] uint16; plane=0 -> one row per symbol, else row = i // plane"""
+def range_decode(payload, rows, n_sym, plane=0, want_bits=False):
+    """rows: [n_rows][CDF_ROW] uint16; plane=0 -> one row per symbol, else row = i // plane.
+    want_bits: -> (sym, bits consumed); an intact stream has len(payload) == (bits + 2 + 7) // 8 (include/aivc_hip.h)"""
     rows = np.ascontiguousarray(rows, np.uint16)
     buf = np.frombuffer(payload, np.uint8)
     padded = np.zeros((len(buf) + 3) // 4 * 4 + 8, np.uint8)
@@ -444,9 +446,10 @@ def range_decode(payload, rows, n_sym, plane=0):
     b.n_streams = 1
     s = b.s[0]
     s.in_off, s.out_off, s.row_off, s.n_sym, s.in_len, s.plane = 0, 0, 0, n_sym, len(buf), plane
-    _chk(lib()['aivc_range_decode'](_p(padded), _p(rows), C.byref(b), _p(sym), None),
+    bits = np.zeros(1, np.uint32)
+    _chk(lib()['aivc_range_decode'](_p(padded), _p(rows), C.byref(b), _p(sym), _p(bits), None),
          'aivc_range_decode')
-    return sym
+    return (sym, int(bits[0])) if want_bits else sym
 
 
 def scatter_symbols(sym, npix, c, maps):

@@ -304,6 +304,23 @@ def test_hip_decode_video_equals_reference_decoder(case, cuda, golden, monkeypat
             assert diff.max() <= 1, (case, k)
             n_off += int((diff != 0).sum())
     assert n_off <= _pixel_budget(m, _frames(g, m, 'dec'))
+    assert fc.stream_errors() == []  # every section's bit count accounts for its payload: decoded on the writer's track
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['decoder_big_gop8', 'decoder_mid_gop8'])
+def test_hip_free_running_desync_is_reported(case, cuda, golden):
+    """The reference-written streams of the writer's-sigma cases decoded WITHOUT the writer's sigma: this build's h_s
+    differs from torch's in the last bits of sigma, some coded symbol meets a flipped CDF bound and the range decoder
+    leaves the writer's track (tests above: test_free_running_statistic_of_teacher_sigma_cases) -- silently, as with
+    torchac.  The product's length check must say so."""
+    g = golden(case)
+    model = _model(golden, case, cuda)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        fc.decode_video(np.asarray(g['video_file']).tobytes(), cuda)
+    errs = fc.stream_errors()
+    assert errs and all(e[1] == 'y latent' for e in errs)  # z sections (integer table) always decode
 
 
 @pytest.mark.gpu

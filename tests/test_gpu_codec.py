@@ -475,3 +475,51 @@ def test_full_module_pickle_load_model_round_trip(cuda, tmp_path):
         dec_a, _, _, _ = a.decode_video(blob_a, cuda)
         dec_b, _, _, _ = b.decode_video(blob_a, cuda)
     assert all(torch.equal(x[k], y[k]) for x, y in zip(dec_a, dec_b) for k in 'yuv')
+
+
+def test_stream_check_clean_and_damaged(cuda, tmp_path, capsys):
+    """The decoder's bit count against the section length (include/aivc_hip.h, aivc_range_decode): a stream this
+    encoder wrote decodes clean; the same stream with one payload byte of a y section changed still "decodes"
+    (the range coder has no error state, torchac's neither) but is reported -- by FrameCodec.stream_errors(), by
+    decode_one_video's [WARN], and by the decode CLI's exit status."""
+    from aivc_amd import synth
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.models import arch
+    from aivc_amd.real_life import cat_binary_files as cont
+    from aivc_amd.real_life import decode as rl_decode
+    from aivc_amd.real_life.bitstream import split_sections
+    from aivc_amd.model_mngt.model_management import attach_arithmetic_coders
+    model = attach_arithmetic_coders(synth.make_model(arch.TINY_WIDTHS, seed=11, device=cuda), cuda)
+    frames = synth.to_device_frames(synth.synthetic_video(96, 64, 9, noise=2.0), cuda)
+    fc = FrameCodec(model)
+    with torch.no_grad():
+        blob = fc.assemble_video(fc.encode_video(frames, '1_GOP_8'))
+        dec, _, _, _ = fc.decode_video(blob, cuda)
+    assert fc.stream_errors() == []
+    assert fc.stream_errors() == []  # (the queue was drained)
+    # damage: one byte in the middle of the I frame's codecnet_y coded payload
+    _, _, _, gops = cont.unpack_video(blob)
+    f0 = cont.unpack_gop(gops[0])[2][0]
+    sy = split_sections(f0)[3]
+    assert len(sy) > 1 + sy[0] + 16
+    pos = f0.index(sy) + 1 + sy[0] + (len(sy) - 1 - sy[0]) // 3
+    bad_f0 = bytearray(f0)
+    bad_f0[pos] ^= 0x5A
+    bad = blob.replace(f0, bytes(bad_f0), 1)
+    assert bad != blob and len(bad) == len(blob)
+    with torch.no_grad():
+        dec2, _, _, _ = fc.decode_video(bad, cuda)
+    errs = fc.stream_errors()
+    assert errs and errs[0][0] == 'codecnet' and errs[0][1] == 'y latent'
+    assert any(not torch.equal(a['y'], b['y']) for a, b in zip(dec, dec2))
+    # the driver with the reference's name prints the warning and leaves the verdict for the CLI
+    path = tmp_path / 'bad.bin'
+    path.write_bytes(bad)
+    out = rl_decode.decode_one_video({'decoder': rl_decode.Decoder({'full_net': model}), 'bitstream_path': str(path),
+                                      'device': str(cuda), 'out_file': str(tmp_path / 'bad.yuv')})
+    assert len(out) == 9 and rl_decode.STREAM_ERRORS
+    assert '[WARN]' in capsys.readouterr().out
+    (tmp_path / 'ok.bin').write_bytes(blob)
+    rl_decode.decode_one_video({'decoder': rl_decode.Decoder({'full_net': model}), 'bitstream_path': str(tmp_path / 'ok.bin'),
+                                'device': str(cuda), 'out_file': ''})
+    assert rl_decode.STREAM_ERRORS == [] and '[WARN]' not in capsys.readouterr().out

@@ -233,8 +233,11 @@ def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
     ref_sym = oracle.range_decode(ref_bytes, rows, n_sym)
     want = (q.reshape(-1, c).T.reshape(-1)[:n_sym].astype(np.int32) + 256).astype(np.uint16)
     np.testing.assert_array_equal(ref_sym, want)
-    got_sym = ops.range_decode([ref_bytes], T(rows.view(np.int16), cuda), [0], [n_sym], [0])[0]
-    eq(got_sym, ref_sym)
+    got_sym, bits = ops.range_decode([ref_bytes], T(rows.view(np.int16), cuda), [0], [n_sym], [0], want_bits=True)
+    eq(got_sym[0], ref_sym)
+    # bits shifted in by renormalisation: same count as the oracle's, and it accounts for the payload length
+    _, ref_bits = oracle.range_decode(ref_bytes, rows, n_sym, want_bits=True)
+    assert int(bits.cpu()[0]) == ref_bits and len(ref_bytes) == (ref_bits + 2 + 7) // 8
 
 
 @pytest.mark.parametrize('scale', [0.4, 3.0, 40.0])
@@ -258,8 +261,9 @@ def test_range_decode_from_windows(scale, oracle, cuda):
     win, sp = ops.laplace_cdf_windows(T(sig, cuda), maps)
     eq(win, win_o)
     eq(sp, sp_o)
-    got = ops.range_decode([payload], win, [0], [n_sym], [0], sigma_pos=sp)[0]
-    eq(got, want)
+    got, bits = ops.range_decode([payload], win, [0], [n_sym], [0], sigma_pos=sp, want_bits=True)
+    eq(got[0], want)
+    assert len(payload) == (int(bits.cpu()[0]) + 2 + 7) // 8
     if scale >= 40.0:
         assert (np.abs(q[..., maps]) > 32).any(), 'the slow path (symbol outside the window) must be exercised'
 
