@@ -91,6 +91,7 @@ PROTOTYPES = {
     'aivc_frame_to_yuv420': [_f, _i32, _i32, _i32, _i32, _f, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f],
     'aivc_downsample2x': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'aivc_warp_blend': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],
+    'aivc_warp_blend_rows': [_f, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _f, _i32, _f, _f],
     'aivc_warp': [_f, _f, _i32, _i32, _i32, _i32, _f],
     'aivc_hyper_params': [_f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f],
     'aivc_channel_gain': [_f, _f, _sz, _i32, _f],

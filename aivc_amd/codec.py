@@ -109,6 +109,83 @@ class FrameCodec:
             aux['code'] = ops.yuv420_to_444(cur_p['y'], cur_p['u'], cur_p['v'], c_store=3)
         return {'sections': sections, 'rec': recs, 'data_dim': data_dim, 'aux': aux}
 
+    # ---- one frame in row bands over the ranks of a unit group (aivc_amd/bands.py) --------------------------------
+    def _band_frame(self, bands, h):
+        """fix the row partition for a frame of h rows: the y grid's rows are split evenly over the ranks"""
+        from .bands import count_down
+        k = count_down(self.cod.g_a)
+        h_y = h
+        for _ in range(k):
+            h_y = (h_y + 1) // 2
+        bands.set_frame(h_y, k)
+        return k
+
+    def _band_motion(self, bands, y_hat_mof, prev, nxt, frame_type, h, w, kf):
+        """MOFNet synthesis + motion compensation in bands -> (pred band, skip band) of this rank's frame rows"""
+        from .bands import Band, BandImages
+        prev444 = self.to444(prev)
+        next444 = self.to444(nxt) if frame_type == FRAME_B else torch.zeros_like(prev444)
+        short_in = BandImages(bands, (prev, nxt), h, w, kf) if frame_type == FRAME_B else None
+        mof_out = self.mof.synthesise(y_hat_mof, short_in, bands=bands)
+        b0, b1 = bands.own(kf, h)
+        if b1 > b0:
+            wb = ops.warp_blend(mof_out.t[:, b0 - mof_out.g0:], prev444, next444, h, w, frame_type, co=4, rows=(b0, b1 - b0))
+            pred, skip = wb['pred'], wb['skip']
+        else:
+            pred = skip = torch.empty((1, 0, w, 4), dtype=torch.float32, device=prev444.device)
+        return Band(bands, pred, b0, h, kf, b0, b1), Band(bands, skip, b0, h, kf, b0, b1)
+
+    def _band_reconstruct(self, bands, cod_out, skip, h, w, kf):
+        """this rank's rows of the 8-bit reconstruction, then the whole planes on every rank (they are references)"""
+        b0, b1 = bands.own(kf, h)
+        dev = cod_out.t.device
+        planes = None
+        if b1 > b0:
+            _, rec8 = ops.frame_to_yuv420(cod_out.rows(b0, b1), b1 - b0, w, skip=None if skip is None else skip.rows(b0, b1),
+                                          want_float=False)
+            planes = dict(zip('yuv', rec8))
+        return bands.gather_planes(planes, h, w)
+
+    def encode_banded(self, cur, prev, nxt, frame_type, idx_rate, bands, on_sections=None):
+        """encode_batch for ONE frame whose transforms are spread in row bands over the ranks of `bands`
+        (every rank passes the same frames).  The latents (all-gathered) and hence the sections are identical on all
+        ranks; the caller lets one of them range-code.  -> like encode_batch (one frame)."""
+        from .bands import BandImages
+        h, w = cur['y'].shape[-2:]
+        kf = self._band_frame(bands, h)
+        sections = [[None] * 4]
+        pred = skip = None
+        if frame_type != FRAME_I:
+            nx = nxt if frame_type == FRAME_B else None
+            a = self.mof.analyse(BandImages(bands, (cur, prev, nx), h, w, kf), frame_type, idx_rate, bands=bands)
+            sections[0][0], sections[0][1] = self.mof.ac.pend_z(a['q_z'])[0], self.mof.ac.pend_y(a['q_y'], a['sigma'])[0]
+            pred, skip = self._band_motion(bands, a['y_hat'], prev, nxt, frame_type, h, w, kf)
+        c = self.cod.analyse(BandImages(bands, (cur, pred), h, w, kf), frame_type, idx_rate, bands=bands)
+        sections[0][2], sections[0][3] = self.cod.ac.pend_z(c['q_z'])[0], self.cod.ac.pend_y(c['q_y'], c['sigma'])[0]
+        if on_sections is not None:
+            on_sections(sections)
+        cod_out = self.cod.synthesise(c['y_hat'], None if pred is None else BandImages(bands, (pred,), h, w, kf), bands=bands)
+        rec = self._band_reconstruct(bands, cod_out, skip, h, w, kf)
+        data_dim = {'x': (h, w), 'y': c['dim_y'], 'z': c['dim_z'], 'x_uv': (math.ceil(h / 2), math.ceil(w / 2))}
+        return {'sections': sections, 'rec': [rec], 'data_dim': data_dim, 'aux': {}}
+
+    def synthesise_banded(self, y_hats, prev, nxt, frame_type, data_dim, bands):
+        """synthesise_batch for ONE frame in row bands (y_hats: the frame's decoded latents, on every rank)"""
+        from .bands import BandImages
+        h, w = data_dim['x']
+        kf = self._band_frame(bands, h)
+        pred = skip = None
+        if frame_type != FRAME_I:
+            pred, skip = self._band_motion(bands, y_hats['mof'], prev, nxt, frame_type, h, w, kf)
+        cod_out = self.cod.synthesise(y_hats['cod'], None if pred is None else BandImages(bands, (pred,), h, w, kf), bands=bands)
+        return self._band_reconstruct(bands, cod_out, skip, h, w, kf)
+
+    @staticmethod
+    def _banded(shard, n_frames):
+        """a dependency level with fewer frames than the group has ranks is coded frame by frame in row bands over
+        all of them (configs[4]: the 1-, 1-, 1-, 2-, 4-frame levels of a single 4K unit on 8 GPUs)"""
+        return shard is not None and shard.R > 1 and n_frames < shard.R and getattr(shard, 'band_levels', True)
+
     def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
         out = self.encode_batch([cur], [prev], [nxt], frame_type, idx_rate, want_aux)
         res = {'bytes': finalize_frames(out['sections'])[0], 'rec': out['rec'][0], 'data_dim': out['data_dim']}
@@ -249,7 +326,21 @@ class FrameCodec:
         for li, level in enumerate(coding_levels(gop)):
             n_levels = li + 1
             pending = []
-            for ftype, chunk in self._chunks(gop, level, range(len(units)), shard):
+            banded = self._banded(shard, len(units) * len(level))
+            if banded:  # every rank of the group works on every frame of the level, a band of rows each
+                bands = shard.bands()
+                for ftype, chunk in self._chunks(gop, level, range(len(units)), None):
+                    for u, f in chunk:
+                        preps = []
+                        keep = shard.local == 0  # identical sections everywhere: the group's first rank codes them
+                        out = self.encode_banded(units[u][frame_index(f)], rec[u].get(gop[f]['prev_ref']),
+                                                 rec[u].get(gop[f]['next_ref']), ftype, idx_rate, bands,
+                                                 on_sections=(lambda secs: preps.append(prepare_finalize(secs))) if keep else None)
+                        data_dim = out['data_dim']
+                        rec[u][f] = out['rec'][0]
+                        if keep:
+                            pending.append(([(u, f)], out['sections'], preps[0]))
+            for ftype, chunk in ([] if banded else self._chunks(gop, level, range(len(units)), shard)):
                 # the flags of the batch start their trip to the host as soon as its latents are quantised, i.e.
                 # before its CodecNet synthesis is queued: the LAST level's range coding then runs under that level's
                 # own synthesis instead of after it (it was the exposed tail of the encoder)
@@ -265,7 +356,7 @@ class FrameCodec:
             # entropy coding runs on the side streams one level behind the transforms: the host picks the flags
             # up (and launches the range coder) only after the next level's transforms are queued, so the main
             # stream never drains on that wait
-            if split:  # every rank of the group needs this level's reconstructions before the next level
+            if split and not banded:  # every rank of the group needs this level's reconstructions before the next level
                 h, w = units[0][0]['y'].shape[-2:]
                 for ftype in sorted({gop[f]['type'] for f in level}):
                     every = [(u, f) for u in range(len(units)) for f in level if gop[f]['type'] == ftype]
@@ -329,8 +420,8 @@ class FrameCodec:
             def issue_entropy(level):
                 for ftype in sorted({gop[f]['type'] for f in level}):
                     items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
-                    if shard is not None:
-                        items = shard.mine(items)
+                    if shard is not None and not self._banded(shard, len(members) * len(level)):
+                        items = shard.mine(items)  # (a banded level's latents are decoded by every rank: no exchange)
                     for s0 in range(0, len(items), self.entropy_chunk):
                         chunk = items[s0:s0 + self.entropy_chunk]
                         pair = [sides[(rr[0] + k) % len(sides)] for k in range(2)]
@@ -351,7 +442,18 @@ class FrameCodec:
             for li, level in enumerate(levels):
                 if li + ahead < len(levels):
                     issue_entropy(levels[li + ahead])
-                for ftype, chunk in self._chunks(gop, level, members, shard):
+                banded = self._banded(shard, len(members) * len(level))
+                if banded:
+                    bands = shard.bands()
+                    for ftype, chunk in self._chunks(gop, level, members, None):
+                        for it in chunk:
+                            for ev in ready[it]:
+                                main.wait_event(ev)
+                            i, f = it
+                            rec[i][f] = self.synthesise_banded(lat[it], rec[i].get(gop[f]['prev_ref']),
+                                                               rec[i].get(gop[f]['next_ref']), ftype, data_dim, bands)
+                            del lat[it]
+                for ftype, chunk in ([] if banded else self._chunks(gop, level, members, shard)):
                     for ev in {id(e): e for it in chunk for e in ready[it]}.values():
                         main.wait_event(ev)
                     yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
@@ -361,7 +463,7 @@ class FrameCodec:
                     for (i, f), r in zip(chunk, dec):
                         rec[i][f] = r
                         del lat[(i, f)]
-                if shard is not None and shard.R > 1:
+                if shard is not None and shard.R > 1 and not banded:
                     h, w = data_dim['x']
                     for ftype in sorted({gop[f]['type'] for f in level}):
                         every = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]

@@ -268,11 +268,13 @@ struct BlendArgs {
   const float *mof, *prev, *next;
   int hm, wm, cm, cr, n, h, w, frame_type, co;
   float *pred, *skip, *x_warp, *alpha_out, *beta_out;
+  int row0, rows;  // the launch covers frame rows [row0, row0 + rows); mof and the outputs are indexed by the LOCAL row
 };
 __global__ __launch_bounds__(256) void warp_blend_kernel(BlendArgs a) {
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= (size_t)a.n * a.h * a.w) return;
-  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.h), b = (int)(pix / ((size_t)a.w * a.h));
+  if (pix >= (size_t)a.n * a.rows * a.w) return;
+  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.rows), b = (int)(pix / ((size_t)a.w * a.rows));
+  const int gr = a.row0 + r;  // row of the frame
   const float *m = a.mof + (((size_t)b * a.hm + r) * a.wm + q) * a.cm;
   float alpha = m[0] + 0.5f;
   alpha = alpha < 0.0f ? 0.0f : (alpha > 1.0f ? 1.0f : alpha);
@@ -288,8 +290,8 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(BlendArgs a) {
   if (a.beta_out) a.beta_out[pix] = beta;
   const float *pimg = a.prev + (size_t)b * a.h * a.w * a.cr;
   const float *nimg = a.next + (size_t)b * a.h * a.w * a.cr;
-  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, r, q);
-  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, r, q);
+  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, gr, q);
+  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, gr, q);
   for (int ch = 0; ch < a.co; ++ch) {
     float xw = 0.0f, pr = 0.0f, sk = 0.0f;
     if (ch < 3) {
@@ -331,8 +333,9 @@ __device__ __forceinline__ void warp_apply4(const float *img, const WarpTap &t, 
 }
 __global__ __launch_bounds__(256) void warp_blend4_kernel(BlendArgs a) {
   const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= (size_t)a.n * a.h * a.w) return;
-  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.h), b = (int)(pix / ((size_t)a.w * a.h));
+  if (pix >= (size_t)a.n * a.rows * a.w) return;
+  const int q = (int)(pix % a.w), r = (int)((pix / a.w) % a.rows), b = (int)(pix / ((size_t)a.w * a.rows));
+  const int gr = a.row0 + r;  // row of the frame
   const float2 *m = reinterpret_cast<const float2 *>(a.mof + (((size_t)b * a.hm + r) * a.wm + q) * a.cm);
   const float2 m01 = m[0], m23 = m[1], m45 = m[2];
   float alpha = m01.x + 0.5f;
@@ -349,8 +352,8 @@ __global__ __launch_bounds__(256) void warp_blend4_kernel(BlendArgs a) {
   if (a.beta_out) a.beta_out[pix] = beta;
   const float *pimg = a.prev + (size_t)b * a.h * a.w * 4;
   const float *nimg = a.next + (size_t)b * a.h * a.w * 4;
-  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, r, q);
-  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, r, q);
+  const WarpTap tp = warp_taps(a.h, a.w, vpx, vpy, gr, q);
+  const WarpTap tn = warp_taps(a.h, a.w, vnx, vny, gr, q);
   float wp[3], wn[3];
   warp_apply4(pimg, tp, wp[0], wp[1], wp[2]);
   warp_apply4(nimg, tn, wn[0], wn[1], wn[2]);
@@ -547,21 +550,32 @@ AIVC_EXPORT int aivc_warp(const float *x, const float *flow, int32_t n, int32_t 
   return check_launch("warp");
 }
 
+AIVC_EXPORT int aivc_warp_blend_rows(const float *mof, int32_t hm, int32_t wm, int32_t cm, const float *prev,
+                                     const float *next, int32_t cr, int32_t n, int32_t h, int32_t w, int32_t row0,
+                                     int32_t rows, int32_t frame_type, float *pred, float *skip, float *x_warp,
+                                     int32_t co, float *alpha_out, float *beta_out, aivc_stream_t stream) {
+  if (!mof || !prev || !next || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
+  if (row0 < 0 || rows < 0 || row0 + rows > h) return AIVC_ERR_ARG;
+  if (hm < rows || wm < w || cm < 6 || cr < 3 || co < 3) return AIVC_ERR_ARG;
+  if (rows == 0) return AIVC_OK;
+  BlendArgs a{mof, prev, next, hm, wm, cm, cr, n, h, w, frame_type, co, pred, skip, x_warp, alpha_out, beta_out, row0, rows};
+  auto al16 = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (cr == 4 && co == 4 && cm % 2 == 0 && (reinterpret_cast<uintptr_t>(mof) & 7u) == 0 && al16(prev) && al16(next) &&
+      al16(pred) && al16(skip) && al16(x_warp)) {
+    hipLaunchKernelGGL(warp_blend4_kernel, dim3(cdiv((size_t)n * rows * w, 256)), dim3(256), 0, to_stream(stream), a);
+    return check_launch("warp_blend");
+  }
+  hipLaunchKernelGGL(warp_blend_kernel, dim3(cdiv((size_t)n * rows * w, 256)), dim3(256), 0, to_stream(stream), a);
+  return check_launch("warp_blend");
+}
+
 AIVC_EXPORT int aivc_warp_blend(const float *mof, int32_t hm, int32_t wm, int32_t cm, const float *prev,
                                 const float *next, int32_t cr, int32_t n, int32_t h, int32_t w, int32_t frame_type,
                                 float *pred, float *skip, float *x_warp, int32_t co, float *alpha_out,
                                 float *beta_out, aivc_stream_t stream) {
-  if (!mof || !prev || !next || n <= 0 || h <= 0 || w <= 0) return AIVC_ERR_ARG;
-  if (hm < h || wm < w || cm < 6 || cr < 3 || co < 3) return AIVC_ERR_ARG;
-  BlendArgs a{mof, prev, next, hm, wm, cm, cr, n, h, w, frame_type, co, pred, skip, x_warp, alpha_out, beta_out};
-  auto al16 = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  if (cr == 4 && co == 4 && cm % 2 == 0 && (reinterpret_cast<uintptr_t>(mof) & 7u) == 0 && al16(prev) && al16(next) &&
-      al16(pred) && al16(skip) && al16(x_warp)) {
-    hipLaunchKernelGGL(warp_blend4_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), a);
-    return check_launch("warp_blend");
-  }
-  hipLaunchKernelGGL(warp_blend_kernel, dim3(cdiv((size_t)n * h * w, 256)), dim3(256), 0, to_stream(stream), a);
-  return check_launch("warp_blend");
+  if (hm < h) return AIVC_ERR_ARG;
+  return aivc_warp_blend_rows(mof, hm, wm, cm, prev, next, cr, n, h, w, 0, h, frame_type, pred, skip, x_warp, co,
+                              alpha_out, beta_out, stream);
 }
 
 AIVC_EXPORT int aivc_hyper_params(const float *hs, int32_t n, int32_t hh, int32_t wh, int32_t c, int32_t h, int32_t w,

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn import Conv2d, ConvTranspose2d, LeakyReLU, ReLU, ReplicationPad2d, Sequential
 
-from ... import abi, ops
+from ... import abi, bands, ops
 from .._cache import cached
 from .misc_layers import GDN
 
@@ -57,7 +57,17 @@ def run_conv(conv, x, pad, act1=abi.ACT_NONE, act2=abi.ACT_NONE, res=None, mul=N
     """x NHWC -> NHWC through one aivc_conv2d launch for a torch Conv2d / ConvTranspose2d.
     gdn: optional GDN module applied to the conv output (fused into the epilogue when possible).
     tail: optional 1x1 Conv2d applied to act1(conv(x)) in the same launch when possible; res / act2 then
-    belong to the tail."""
+    belong to the tail.
+    x may be a row band of the map (aivc_amd/bands.py: one frame over the ranks of a unit group): the same launch then
+    runs on this rank's slab (band + halo rows fetched from the neighbours) and a band comes back."""
+    if isinstance(x, (bands.Band, bands.BandImages)):
+        transposed = isinstance(conv, ConvTranspose2d)
+
+        def launch(xs, rs, ms):
+            return run_conv(conv, xs, pad, act1=act1, act2=act2, res=rs, mul=ms, gdn=gdn, tail=tail)
+        return x.ctx.conv(launch, x, abi.MODE_TCONV if transposed else abi.MODE_CONV, _sq(conv.kernel_size),
+                          _sq(conv.stride), 0 if transposed else pad,
+                          (tail if tail is not None else conv).out_channels, res=res, mul=mul)
     c_store = (x.shape[-1] + 3) // 4 * 4
     w, b = packed_conv(conv, c_store, x.device, getattr(x, '_aivc_cmap', None))
     if tail is not None:

@@ -66,19 +66,26 @@ class ConditionalNet(Module):
             return self.gain_I
         return self.gain_P if frame_type == FRAME_P else self.gain_B
 
-    def shortcut(self, in_shortcut, n, h_y, w_y, device):
+    def shortcut(self, in_shortcut, n, h_y, w_y, device, bands=None):
         """g_a_ref(in_shortcut) or the all-zero dummy (src/real_life/decode.py:887-892)."""
         if in_shortcut is not None and getattr(self, 'g_a_ref', None) is not None:
             s = run_nhwc(self.g_a_ref, in_shortcut)
+            if bands is not None:  # computed in row bands over the ranks of the group: every rank gets the whole latent
+                s = bands.gather_full(s)
             return s[:, :h_y, :w_y, :].contiguous() if s.shape[1:3] != (h_y, w_y) else s
         return torch.zeros((n, h_y, w_y, self.out_c_shortcut_y), dtype=torch.float32, device=device)
 
-    def analyse(self, x_in, frame_type, idx_rate=0.):
+    def analyse(self, x_in, frame_type, idx_rate=0., bands=None):
         """Encoder side up to the quantised latents.  x_in NHWC.  Returns a dict with q_z / q_y
-        (int16 NHWC), sigma, mu, y_hat (already multiplied by the decoder gain) and the latent sizes."""
+        (int16 NHWC), sigma, mu, y_hat (already multiplied by the decoder gain) and the latent sizes.
+        bands (aivc_amd.bands.BandCtx): x_in is a banded input; g_a runs in row bands over the ranks of the group, y is
+        all-gathered and the hyperprior + quantisation run on every rank alike (identical results: fixed-order
+        arithmetic)."""
         gm = self.gain_module(frame_type)
         dev = x_in.device
         y = run_nhwc(self.g_a, x_in)
+        if bands is not None:
+            y = bands.gather_full(y)
         y = ops.channel_gain(y, gm.gain_vector(idx_rate, 'enc').to(dev))
         z = run_nhwc(self.h_a, y)
         q_z, z_hat = ops.quantize_center(z)
@@ -96,7 +103,9 @@ class ConditionalNet(Module):
         q_y = q_y_fn(sigma)
         return ops.dequantize(q_y, mu, gm.gain_vector(idx_rate, 'dec').to(q_z.device))
 
-    def synthesise(self, y_hat, in_shortcut):
+    def synthesise(self, y_hat, in_shortcut, bands=None):
+        """bands: g_a_ref and g_s run in row bands; -> this rank's band of the synthesis output"""
         n, h_y, w_y, _ = y_hat.shape
-        s = self.shortcut(in_shortcut, n, h_y, w_y, y_hat.device)
-        return run_nhwc(self.g_s, torch.cat((y_hat, s), dim=3))
+        s = self.shortcut(in_shortcut, n, h_y, w_y, y_hat.device, bands)
+        x = torch.cat((y_hat, s), dim=3)
+        return run_nhwc(self.g_s, x if bands is None else bands.full(x, 0))

@@ -398,23 +398,27 @@ def warp(x, flow):
     return out
 
 
-def warp_blend(mof, prev, nxt, h, w, frame_type, co=4, want_aux=False):
+def warp_blend(mof, prev, nxt, h, w, frame_type, co=4, want_aux=False, rows=None):
+    """rows = (row0, n_rows): only that band of the frame -- mof is then the band of the MOFNet output (its row 0 =
+    frame row row0), prev / nxt stay whole frames, the outputs are [n, n_rows, w, co] (aivc_warp_blend_rows)."""
     mof, prev, nxt = (_dev(t, torch.float32, nm) for t, nm in ((mof, 'mof'), (prev, 'prev'), (nxt, 'next')))
     n, hm, wm, cm = mof.shape
     dev = mof.device
-    pred = torch.empty((n, h, w, co), dtype=torch.float32, device=dev)
+    row0, nr = (0, h) if rows is None else rows
+    pred = torch.empty((n, nr, w, co), dtype=torch.float32, device=dev)
     skip = torch.empty_like(pred)
     xw = alpha = beta = None
     if want_aux:
         xw = torch.empty_like(pred)
-        alpha = torch.empty((n, h, w), dtype=torch.float32, device=dev)
-        beta = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+        alpha = torch.empty((n, nr, w), dtype=torch.float32, device=dev)
+        beta = torch.empty((n, nr, w), dtype=torch.float32, device=dev)
     # algorithmic bytes (SURVEY 8d): the 6 MOFNet maps, 3 channels of each reference used, pred + skip out
     n_ref = 2 if int(frame_type) == FRAME_B else 1
-    nb = n * h * w * 4 * (6 + 3 * n_ref + 2 * co + ((co + 2) if want_aux else 0))
+    nb = n * nr * w * 4 * (6 + 3 * n_ref + 2 * co + ((co + 2) if want_aux else 0))
     _hbm_profiled('warp_blend', nb,
-                  lambda: call('aivc_warp_blend', _p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
-                               int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha), _p(beta), _stream()))
+                  lambda: call('aivc_warp_blend_rows', _p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
+                               int(row0), int(nr), int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha), _p(beta),
+                               _stream()))
     return {'pred': pred, 'skip': skip, 'x_warp': xw, 'alpha': alpha, 'beta': beta}
 
 

@@ -221,6 +221,16 @@ class ClipShard:
     def mine(self, items):
         return items[self.local::self.R]
 
+    def bands(self):
+        """row-band context of this rank's group (aivc_amd/bands.py): levels with fewer frames than the group has
+        ranks are coded one frame at a time, every rank a band of rows (FrameCodec._banded)"""
+        if getattr(self, '_bands', None) is None:
+            from .bands import BandCtx, DistComm
+            ranks = list(range(self.group_id * self.R, (self.group_id + 1) * self.R))
+            dev = self.device if self.device is not None else torch.device('cuda', torch.cuda.current_device())
+            self._bands = BandCtx(DistComm(self.pg, ranks, self.local), dev)
+        return self._bands
+
     # ---- exchanges inside the group ------------------------------------------------------------------------
     def exchange_frames(self, items, my_recs, h, w, device):
         """items: every frame of a level (same order on all ranks of the group); my_recs: reconstructions of

@@ -222,6 +222,16 @@ int aivc_warp_blend(const float *mof, int32_t hm, int32_t wm, int32_t cm, const 
                     int32_t frame_type, float *pred, float *skip, float *x_warp, int32_t co,
                     float *alpha_out, float *beta_out, aivc_stream_t stream);
 
+/* The same for a BAND of output rows [row0, row0 + rows) of the frame (one frame's row bands spread over several
+ * GPUs): mof is the band of the MOFNet output, [n][hm][wm][cm] with its local row 0 = frame row row0
+ * (hm >= rows); prev / next are the WHOLE references [n][h][w][cr] (motion vectors reach anywhere);
+ * pred / skip / x_warp are [n][rows][w][co], alpha_out / beta_out [n][rows][w].  Row r of the outputs is bit-identical
+ * to row row0 + r of aivc_warp_blend on the whole frame. */
+int aivc_warp_blend_rows(const float *mof, int32_t hm, int32_t wm, int32_t cm, const float *prev,
+                         const float *next, int32_t cr, int32_t n, int32_t h, int32_t w, int32_t row0, int32_t rows,
+                         int32_t frame_type, float *pred, float *skip, float *x_warp, int32_t co,
+                         float *alpha_out, float *beta_out, aivc_stream_t stream);
+
 /* Stand-alone warp (src/func_util/optical_flow.py:14-55): x [n][h][w][c], flow [n][h][w][2]
  * (channel 0 = horizontal, 1 = vertical, pixel units) -> out [n][h][w][c]. */
 int aivc_warp(const float *x, const float *flow, int32_t n, int32_t h, int32_t w, int32_t c,

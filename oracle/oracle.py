@@ -263,17 +263,19 @@ def warp(x, flow):
     return out
 
 
-def warp_blend(mof, prev, nxt, h, w, frame_type, co=4):
+def warp_blend(mof, prev, nxt, h, w, frame_type, co=4, rows=None):
+    """rows = (row0, n_rows): the band twin (aivc_warp_blend_rows): mof is the band, prev / nxt whole frames"""
     mof, prev, nxt = _f32(mof), _f32(prev), _f32(nxt)
     n, hm, wm, cm = mof.shape
-    pred = np.empty((n, h, w, co), np.float32)
+    row0, nr = (0, h) if rows is None else rows
+    pred = np.empty((n, nr, w, co), np.float32)
     skip = np.empty_like(pred)
     xw = np.empty_like(pred)
-    alpha = np.empty((n, h, w), np.float32)
-    beta = np.empty((n, h, w), np.float32)
-    _chk(lib()['aivc_warp_blend'](_p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w,
-                                  int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha),
-                                  _p(beta), None), 'aivc_warp_blend')
+    alpha = np.empty((n, nr, w), np.float32)
+    beta = np.empty((n, nr, w), np.float32)
+    _chk(lib()['aivc_warp_blend_rows'](_p(mof), hm, wm, cm, _p(prev), _p(nxt), prev.shape[-1], n, h, w, int(row0), int(nr),
+                                       int(frame_type), _p(pred), _p(skip), _p(xw), co, _p(alpha),
+                                       _p(beta), None), 'aivc_warp_blend_rows')
     return {'pred': pred, 'skip': skip, 'x_warp': xw, 'alpha': alpha, 'beta': beta}
 
 
