@@ -115,8 +115,11 @@ class DistComm:
             buf = torch.empty(view.shape, dtype=view.dtype) if self.host else (view if view.is_contiguous() else torch.empty_like(view))
             staged.append((view, buf))
             p2p.append(d.P2POp(d.irecv, buf, self.ranks[src], group=self.pg))
-        for w in d.batch_isend_irecv(p2p):
-            w.wait()
+        from . import parallel
+        parallel._note('halo exchange (%d sends, %d receives)' % (len(sends), len(recvs)))
+        with parallel._host_wait('halo exchange'):
+            for w in d.batch_isend_irecv(p2p):
+                w.wait()
         for view, buf in staged:
             if buf is not view:
                 view.copy_(buf)
@@ -128,7 +131,10 @@ class DistComm:
         self.stats['bytes_gathered'] += t.numel() * t.element_size() * (self.R - 1)
         src = t.contiguous().cpu() if self.host else t.contiguous()
         out = torch.empty((self.R,) + tuple(t.shape), dtype=t.dtype, device=src.device)
-        d.all_gather_into_tensor(out.view(-1), src.view(-1), group=self.pg)
+        from . import parallel
+        parallel._note('all_gather band rows %s' % (tuple(t.shape),))
+        with parallel._host_wait('all_gather of band rows'):
+            d.all_gather_into_tensor(out.view(-1), src.view(-1), group=self.pg)
         return out.to(t.device)
 
 

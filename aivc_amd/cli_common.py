@@ -22,11 +22,8 @@ def resolve_device(cpu_flag):
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if not dist.is_initialized():
-        backend = os.environ.get('AIVC_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        from . import parallel
+        parallel.init_process_group(dev)  # RCCL bound to this rank's GPU, finite timeout, watchdog
     if dist.get_rank() != 0:
         from .func_util import console_display
         console_display.FLAG_QUIET = True

@@ -181,10 +181,19 @@ class FrameCodec:
         return self._band_reconstruct(bands, cod_out, skip, h, w, kf)
 
     @staticmethod
-    def _banded(shard, n_frames):
-        """a dependency level with fewer frames than the group has ranks is coded frame by frame in row bands over
-        all of them (configs[4]: the 1-, 1-, 1-, 2-, 4-frame levels of a single 4K unit on 8 GPUs)"""
-        return shard is not None and shard.R > 1 and n_frames < shard.R and getattr(shard, 'band_levels', True)
+    def _banded(shard, n_frames, h, w):
+        """A dependency level with fewer frames than the group has ranks can be coded frame by frame in row bands over
+        all of them (configs[4]: the 1-, 1-, 1-, 2-, 4-frame levels of a single 4K unit on 8 GPUs).  It pays when a
+        band's kernels plus ~70 halo exchanges per frame beat one rank doing the frame alone
+        (profiles/r04_band_stats_*.json: per-rank kernel time 8.5 vs 28.5 ms for a 4K B frame on 8 ranks, but 7.7 vs
+        9.1 ms at 1080p on 2): by default from 4 ranks per group on, or from 2 for frames of >= 6 Mpixel.
+        AIVC_BAND_LEVELS=1 / 0 forces it on / off (every rank must see the same value)."""
+        if shard is None or shard.R <= 1 or n_frames >= shard.R or not getattr(shard, 'band_levels', True):
+            return False
+        force = _os.environ.get('AIVC_BAND_LEVELS')
+        if force is not None:
+            return force not in ('0', '')
+        return shard.R >= 4 or h * w >= 6000000
 
     def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):
         out = self.encode_batch([cur], [prev], [nxt], frame_type, idx_rate, want_aux)
@@ -326,7 +335,7 @@ class FrameCodec:
         for li, level in enumerate(coding_levels(gop)):
             n_levels = li + 1
             pending = []
-            banded = self._banded(shard, len(units) * len(level))
+            banded = self._banded(shard, len(units) * len(level), *units[0][0]['y'].shape[-2:])
             if banded:  # every rank of the group works on every frame of the level, a band of rows each
                 bands = shard.bands()
                 for ftype, chunk in self._chunks(gop, level, range(len(units)), None):
@@ -420,7 +429,7 @@ class FrameCodec:
             def issue_entropy(level):
                 for ftype in sorted({gop[f]['type'] for f in level}):
                     items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
-                    if shard is not None and not self._banded(shard, len(members) * len(level)):
+                    if shard is not None and not self._banded(shard, len(members) * len(level), *data_dim['x']):
                         items = shard.mine(items)  # (a banded level's latents are decoded by every rank: no exchange)
                     for s0 in range(0, len(items), self.entropy_chunk):
                         chunk = items[s0:s0 + self.entropy_chunk]
@@ -442,7 +451,7 @@ class FrameCodec:
             for li, level in enumerate(levels):
                 if li + ahead < len(levels):
                     issue_entropy(levels[li + ahead])
-                banded = self._banded(shard, len(members) * len(level))
+                banded = self._banded(shard, len(members) * len(level), *data_dim['x'])
                 if banded:
                     bands = shard.bands()
                     for ftype, chunk in self._chunks(gop, level, members, None):

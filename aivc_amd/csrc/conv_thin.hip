@@ -340,7 +340,13 @@ static int launch_thin_mfma_g(const aivc_conv_params &p, hipStream_t s) {
     n_cu = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? cus : 256;
   }
   const int cus = n_cu.load(std::memory_order_relaxed);
-  const int grid = ntiles < cus ? ntiles : cus;
+  // More workgroups than CUs (one fits per CU): a group that shares its CU with a range-coder wave of the entropy side
+  // streams runs slower, and with ONE group per CU walking a fixed share of the tiles the slowest CU set the launch
+  // time; with several rounds of groups the hardware dispatcher evens it out (the B operand is re-gathered per group:
+  // 25 x 64 x c_out floats out of L2).  AIVC_THIN_GRID_MULT: tuning aid.
+  static const int mult = getenv("AIVC_THIN_GRID_MULT") ? atoi(getenv("AIVC_THIN_GRID_MULT")) : 1;
+  const int want = cus * (mult > 0 ? mult : 1);
+  const int grid = ntiles < want ? ntiles : want;
   hipLaunchKernelGGL((thin_mfma_kernel<KS, CO, G16>), dim3(grid), dim3(512), lds, s, p, tiles_x, tiles_y, ntiles);
   return check_launch("thin_mfma");
 }

@@ -17,19 +17,104 @@ def rank_world():
     return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
 
 
+# ---- start-up and a watchdog for the first contact with RCCL -------------------------------------------------------
+_TRAIL = []        # the last collectives this rank issued: (name, wall time)
+_WATCH = {'thread': None, 'waiting': None}
+
+
+def init_process_group(device=None, backend=None, timeout_s=None):
+    """torch.distributed start-up for one process per GPU: RCCL ('nccl') bound to `device` (eager communicator
+    creation; sub-groups are split from it), gloo where AIVC_DIST_BACKEND says so (the one-GPU test boxes).  A finite
+    timeout (AIVC_DIST_TIMEOUT_S, default 300 s) so that a rank that never arrives ends the job with PyTorch's
+    collective dump instead of hanging the launcher, and a watchdog thread that names what this rank is waiting in."""
+    import datetime
+    import os
+    if dist.is_initialized():
+        return
+    backend = backend or os.environ.get('AIVC_DIST_BACKEND', 'nccl')
+    timeout = datetime.timedelta(seconds=float(timeout_s or os.environ.get('AIVC_DIST_TIMEOUT_S', '300')))
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=device, timeout=timeout)
+    else:
+        dist.init_process_group(backend, timeout=timeout)
+    _start_watchdog()
+
+
+def _note(name):
+    """record a collective about to be issued (cheap: a list append)"""
+    import time
+    _TRAIL.append((name, time.time()))
+    if len(_TRAIL) > 32:
+        del _TRAIL[:16]
+
+
+class _host_wait:
+    """`with _host_wait('what'):` around a point where the HOST blocks on communication (a .cpu() of a gathered tensor,
+    a barrier, a gloo collective): if it lasts longer than AIVC_DIST_WARN_S (60 s) the watchdog prints, once, which wait
+    it is and the collectives this rank issued before it -- under RCCL the enqueue of a collective returns at once and a
+    missing peer only shows at the next host synchronisation, far from its cause."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import time
+        _WATCH['waiting'] = (self.name, time.time(), False)
+
+    def __exit__(self, *exc):
+        _WATCH['waiting'] = None
+        return False
+
+
+def _start_watchdog():
+    import os
+    import sys
+    import threading
+    import time
+    if _WATCH['thread'] is not None:
+        return
+    warn = float(os.environ.get('AIVC_DIST_WARN_S', '60'))
+
+    def run():
+        while True:
+            time.sleep(min(5.0, warn / 4))
+            w = _WATCH['waiting']
+            if w is not None and not w[2] and time.time() - w[1] > warn:
+                _WATCH['waiting'] = (w[0], w[1], True)
+                trail = ', '.join('%s (%.0f s ago)' % (n, time.time() - t) for n, t in _TRAIL[-6:])
+                sys.stderr.write('[aivc_amd.parallel] rank %d has been waiting %.0f s in "%s"; last collectives issued: %s\n'
+                                 % (dist.get_rank() if dist.is_initialized() else -1, time.time() - w[1], w[0], trail or 'none'))
+                sys.stderr.flush()
+    t = threading.Thread(target=run, name='aivc-dist-watchdog', daemon=True)
+    t.start()
+    _WATCH['thread'] = t
+
+
 def broadcast_model(model, src=0):
-    """One broadcast of every parameter/buffer from `src` (RCCL over xGMI on GPUs, gloo on CPU)."""
+    """ONE broadcast of the weights from `src` (RCCL over xGMI on GPUs, gloo on CPU): every parameter and buffer of a
+    dtype travels in one flat tensor (a real model has ~370 of them; fp32 except the odd integer buffer)."""
     if not is_dist():
         return model
     with torch.no_grad():
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src)
+        tensors = [t.data for t in list(model.parameters()) + list(model.buffers())]
+        by_type = {}
+        for t in tensors:
+            by_type.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, device), ts in by_type.items():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            _note('broadcast weights %s x%d' % (dtype, flat.numel()))
+            dist.broadcast(flat, src)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
     # writing through .data does not bump Parameter._version, which is what the packed-weight / GDN / z-table
     # cache is stamped with: anything cached before the broadcast would stay stale on the receiving ranks
     from .layers import _cache
     _cache.clear()
     if torch.cuda.is_available() and torch.cuda.is_initialized():
-        torch.cuda.synchronize()  # the codec's side streams read the parameters without waiting for this stream
+        with _host_wait('device sync after the weight broadcast'):
+            torch.cuda.synchronize()  # the codec's side streams read the parameters without waiting for this stream
     return model
 
 
@@ -65,8 +150,10 @@ def encode_video_sharded(frame_codec, frames, gop_name, idx_starting_frame=0, id
         cdev = _comm_device(None, dev)
         v = [-1] * 6 if data_dim is None else [*data_dim['x'], *data_dim['y'], *data_dim['z']]
         t = torch.tensor(v, dtype=torch.int64, device=cdev)
+        _note('all_reduce latent sizes')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        v = [int(x) for x in t.cpu()]
+        with _host_wait('latent sizes to the host'):
+            v = [int(x) for x in t.cpu()]
         data_dim = {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
     if gops is None:
         return (None, enc) if return_enc else None
@@ -107,10 +194,12 @@ def decode_video_sharded(frame_codec, blob, device=None):
     if mine:
         torch.cat([f[k].reshape(-1).to(cdev) for f in mine for k in 'yuv'], out=send.view(-1)[:len(mine) * fsz])
     recv = torch.empty((world * per, fsz), dtype=torch.uint8, device=cdev)
+    _note('all_gather decoded planes')
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
     if rank != 0:
         return None
-    recv = recv.cpu()
+    with _host_wait('decoded planes to the host'):
+        recv = recv.cpu()
     out = []
     for r, slot in owner:
         row = recv[r * per + slot]
@@ -150,8 +239,10 @@ def gather_bytes_all(mine, keys, group, n_ranks, device=None):
     cdev = _comm_device(group, device)
     lens = torch.tensor([len(mine[k]) if k in mine else -1 for k in keys], dtype=torch.int64, device=cdev)
     all_lens = torch.empty((n_ranks, len(keys)), dtype=torch.int64, device=cdev)
+    _note('all_gather byte lengths')
     dist.all_gather_into_tensor(all_lens.view(-1), lens, group=group)
-    all_lens = all_lens.cpu()
+    with _host_wait('byte lengths to the host'):
+        all_lens = all_lens.cpu()
     totals = all_lens.clamp_min(0).sum(dim=1)
     cap = max(int(totals.max()), 1)
     payload = bytearray()
@@ -163,8 +254,10 @@ def gather_bytes_all(mine, keys, group, n_ranks, device=None):
         buf[:len(payload)] = torch.frombuffer(payload, dtype=torch.uint8)
     buf = buf.to(cdev)
     recv = torch.empty((n_ranks, cap), dtype=torch.uint8, device=cdev)
+    _note('all_gather byte payload')
     dist.all_gather_into_tensor(recv.view(-1), buf, group=group)
-    recv = recv.cpu().numpy()
+    with _host_wait('byte payload to the host'):
+        recv = recv.cpu().numpy()
     out = {}
     for r in range(n_ranks):
         pos = 0
@@ -211,6 +304,8 @@ class ClipShard:
         if self.world > 1:
             for g in range(self.G):
                 ranks = list(range(g * self.R, (g + 1) * self.R))
+                # every rank calls new_group for EVERY group, in the same order (a collective over the world)
+                _note('new_group %s' % ranks)
                 pg = dist.new_group(ranks) if self.R > 1 else None
                 if g == self.group_id:
                     self.pg = pg
@@ -254,8 +349,10 @@ class ClipShard:
         # asynchronous: under RCCL the gather runs on the communicator's own stream (it waits for the packing on
         # the current stream, nothing else does: the entropy coder's side streams keep running); the current stream
         # joins it at work.wait() -- the frames are the references of the very next level, so that is right away
+        _note('all_gather level reconstructions')
         work = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.pg, async_op=True)  # flat: gloo wants 1-D
-        work.wait()
+        with _host_wait('level reconstructions'):
+            work.wait()
         recv = recv.to(device)
         out = [None] * len(items)
         for j in range(len(items)):
@@ -280,8 +377,10 @@ class ClipShard:
         v = [-1] * 6 if data_dim is None else [*data_dim['x'], *data_dim['y'], *data_dim['z']]
         t = torch.tensor(v, dtype=torch.int64, device=cdev)
         allv = torch.empty((self.R, 6), dtype=torch.int64, device=cdev)
+        _note('all_gather latent sizes (group)')
         dist.all_gather_into_tensor(allv.view(-1), t, group=self.pg)
-        v = [int(x) for x in allv.cpu().max(dim=0).values]
+        with _host_wait('latent sizes (group) to the host'):
+            v = [int(x) for x in allv.cpu().max(dim=0).values]
         return {'x': (v[0], v[1]), 'y': (v[2], v[3]), 'z': (v[4], v[5]), 'x_uv': ((v[0] + 1) // 2, (v[1] + 1) // 2)}
 
     # ---- across the groups ------------------------------------------------------------------------------------

@@ -272,10 +272,8 @@ def main():
                 sk.bind(('127.0.0.1', 0))
                 os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                                   MASTER_PORT=str(sk.getsockname()[1]))
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        from aivc_amd import parallel as _par
+        _par.init_process_group(dev, backend)  # RCCL bound to this rank's GPU, finite timeout, watchdog
     strong = args.scaling == 'strong' or (args.scaling == 'auto')  # the label: same total work whatever N
     sharded = strong and use_dist  # ClipShard path; at N = 1 strong and weak are the same single-process run
 

@@ -38,8 +38,11 @@ def _setup(n_units, gop, w=80, h=48, default_widths=False):
 
 def _worker(rank, world, port, q, n_units, gop, w, h, default_widths):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if w * h < 6000000:
+        os.environ['AIVC_BAND_LEVELS'] = '1'  # small frames: the automatic rule would not band 2 ranks (FrameCodec._banded)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), AIVC_DIST_BACKEND='gloo')
     from aivc_amd import parallel
+    parallel.init_process_group()  # (the product's start-up: timeout + watchdog)
     model, units, dev = _setup(n_units, gop, w, h, default_widths)
     parallel.broadcast_model(model)
     fc = model.frame_codec()

@@ -276,3 +276,23 @@ def test_load_model_resolves_unknown_module_paths_by_class_name(tmp_path, monkey
     (tmp_path / '1_model.pt').write_bytes(raw2)
     with pytest.raises(ImportError, match='models.net.FooBNet'):
         model_management.load_model(prefix='1_', on_cpu=True)
+
+
+def test_distributed_watchdog_names_the_wait(capfd, monkeypatch):
+    """a host-side wait on communication that lasts longer than AIVC_DIST_WARN_S is reported once, with the wait's name
+    and the collectives issued before it (aivc_amd/parallel.py: under RCCL a missing peer only shows at the next host
+    synchronisation, far from its cause)"""
+    import time
+    from aivc_amd import parallel
+    monkeypatch.setenv('AIVC_DIST_WARN_S', '0.2')
+    monkeypatch.setitem(parallel._WATCH, 'thread', None)
+    parallel._start_watchdog()
+    parallel._note('all_gather level reconstructions')
+    with parallel._host_wait('level reconstructions'):
+        time.sleep(0.8)
+    err = capfd.readouterr().err
+    assert err.count('[aivc_amd.parallel]') == 1 and '"level reconstructions"' in err and 'all_gather level reconstructions' in err
+    with parallel._host_wait('quick'):
+        pass
+    time.sleep(0.3)
+    assert '[aivc_amd.parallel]' not in capfd.readouterr().err
