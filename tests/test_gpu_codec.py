@@ -136,6 +136,31 @@ def test_config4_one_full_gop32_unit_1080p(cuda):
     assert enc['nb_gop'] == 1 and len(dec) == 33
 
 
+def test_config5_one_full_gop32_unit_2160p(cuda):
+    """BASELINE configs[4] itself: 3840x2160, 32 frames under RA `1_GOP_32` = ONE 33-frame intra-period unit (the last
+    frame repeated), all 7 dependency levels, with the bench's schedule (a whole level per batch, entropy stages on the
+    side streams two levels ahead) -- decoder == encoder reconstruction for every frame, and every section's range
+    decoder ends where its payload ends (FrameCodec.stream_errors)"""
+    from aivc_amd import synth
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.models import arch
+    model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+    synth.calibrate_operating_point(model, cuda)
+    base = synth.synthetic_video(3840, 2160, 4, seed=9)
+    # 32 frames out of 4 distinct pictures (host RAM: a 4K frame of the generator is 12 MB of float work per call)
+    frames = synth.to_device_frames([base[i % 4] for i in range(32)], cuda)
+    fc = FrameCodec(model, max_batch=16)
+    with torch.no_grad():
+        enc = fc.encode_video(frames, '1_GOP_32')
+        blob = fc.assemble_video(enc)
+        dec, data_dim, first, last = fc.decode_video(blob, cuda)
+    assert enc['nb_gop'] == 1 and (first, last) == (0, 31) and len(dec) == 32 and data_dim['x'] == (2160, 3840)
+    for i, (d, e) in enumerate(zip(dec, enc['recs'][0])):
+        for k in 'yuv':
+            assert torch.equal(d[k], e[k]), (i, k)
+    assert fc.stream_errors() == []
+
+
 def test_config5_2160p_high_rate(cuda):
     """BASELINE configs[4] says "ms_ssim-2 (high rate)": every one of the 64 y maps of both networks non-zero
     (2.1 M coded symbols per latent at 3840x2160) -- closed loop, and the y sections do list all 64 maps."""
