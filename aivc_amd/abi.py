@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -63,6 +63,23 @@ class MapList(C.Structure):
         return m
 
 
+def frame_maps_table(maps_list, npix):
+    """numpy image of an aivc_frame_maps[len(maps_list)] array (include/aivc_hip.h): frame f codes the channels
+    maps_list[f], its positions start where the previous frames' end.  -> (uint8 array [n, 272], [pos_off per frame], total)"""
+    import numpy as np
+    dt = np.dtype([('pos_off', '<u8'), ('n_maps', '<i4'), ('reserved', '<i4'), ('idx', 'u1', (MAX_MAPS,))])
+    t = np.zeros(len(maps_list), dt)
+    offs, pos = [], 0
+    for f, m in enumerate(maps_list):
+        offs.append(pos)
+        t['pos_off'][f] = pos
+        t['n_maps'][f] = len(m)
+        if len(m):
+            t['idx'][f, :len(m)] = np.asarray(list(m), np.uint8)
+        pos += len(m) * npix
+    return t.view(np.uint8).reshape(len(maps_list), dt.itemsize), offs, pos
+
+
 class RcStream(C.Structure):
     _fields_ = [('in_off', C.c_uint64), ('out_off', C.c_uint64), ('row_off', C.c_uint64),
                 ('n_sym', C.c_uint32), ('in_len', C.c_uint32), ('out_cap', C.c_uint32),
@@ -109,6 +126,10 @@ PROTOTYPES = {
     'aivc_range_decode': [_f, _f, _P(RcBatch), _f, _f],
     'aivc_range_decode_windows': [_f, _f, _f, _P(RcBatch), _f, _f],
     'aivc_scatter_symbols': [_f, _sz, _i32, _P(MapList), _f],
+    'aivc_laplace_cdf_windows_batch': [_f, _i32, _sz, _i32, _f, _i32, _f, _f],
+    'aivc_laplace_bounds_batch': [_f, _f, _i32, _sz, _i32, _f, _i32, _f],
+    'aivc_table_bounds_batch': [_f, _f, _i32, _sz, _i32, _f],
+    'aivc_scatter_symbols_batch': [_f, _i32, _sz, _i32, _f, _f],
 }
 
 

@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void table_bounds_kernel(const uint16_t *__res
   bounds[pos] = (uint32_t)row[sym] | (sym == AIVC_MAX_SYMBOL ? 0u : (uint32_t)row[sym + 1] << 16);
 }
 
+__global__ __launch_bounds__(256) void table_bounds_batch_kernel(const uint16_t *__restrict__ table, const int16_t *__restrict__ q,
+                                                                 size_t npix, int c, uint32_t *__restrict__ bounds) {
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (size_t)c * npix) return;
+  const int ch = (int)(pos / npix);
+  const size_t pix = pos % npix;
+  const int sym = min(max((int)q[((size_t)blockIdx.y * npix + pix) * c + ch] + AIVC_AC_MAX_VAL, 0), AIVC_MAX_SYMBOL);
+  const uint16_t *row = table + (size_t)ch * AIVC_CDF_ROW;
+  bounds[(size_t)blockIdx.y * c * npix + pos] = (uint32_t)row[sym] | (sym == AIVC_MAX_SYMBOL ? 0u : (uint32_t)row[sym + 1] << 16);
+}
+
 struct InvMap {
   int16_t slot[AIVC_MAX_MAPS];  // channel -> position in the coded list, or -1
 };
@@ -205,6 +216,104 @@ __global__ __launch_bounds__(256) void scatter_symbols_kernel(const uint16_t *__
   }
   int16_t *dst = q + pix * c + ch0;
   if (vec) {  // c % 8 == 0 and q 16-byte aligned
+    uint4 o;
+    o.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+    o.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+    o.z = (uint32_t)(uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
+    o.w = (uint32_t)(uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+    *reinterpret_cast<uint4 *>(dst) = o;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ch0 + e < c) dst[e] = v[e];
+  }
+}
+
+// ---- frame-batch variants: blockIdx.y = frame, its map list and stream offset read from a device table ------------
+__global__ __launch_bounds__(256) void laplace_cdf_windows_batch_kernel(const float *__restrict__ sigma, size_t npix, int c,
+                                                                        const aivc_frame_maps *__restrict__ frames,
+                                                                        uint16_t *__restrict__ win, float *__restrict__ sigma_pos) {
+  constexpr int CHUNKS = CDF_WIN / 8;
+  const aivc_frame_maps &fm = frames[blockIdx.y];
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)fm.n_maps * npix;
+  const size_t wv = gid >> 6;
+  if ((wv / CHUNKS) * 64 >= total) return;  // wave-uniform
+  const int lane = (int)(gid & 63), chunk = (int)(wv % CHUNKS);
+  const size_t pos = (wv / CHUNKS) * 64 + (size_t)lane;
+  const bool valid = pos < total;
+  const float *sg = sigma + (size_t)blockIdx.y * npix * c;
+  float s = 1.0f;
+  if (valid) {
+    const int m = (int)(pos / npix);
+    const size_t pix = pos % npix;
+    s = sg[pix * c + fm.idx[m]];
+    if (chunk == 0) sigma_pos[fm.pos_off + pos] = s;
+  }
+  const int k0 = CDF_WIN0 + chunk * 8;
+  uint32_t w[4];
+  bool sat = false;
+  if (chunk != CHUNKS / 2) {
+    const float tmin = chunk < CHUNKS / 2 ? 256.5f - (float)(k0 + 7) : (float)k0 - 256.5f;
+    const float b = s / 1.41421354f;
+    sat = tmin / b > 17.5f;
+  }
+  if (__all(sat || !valid)) {
+    const uint32_t base = chunk < CHUNKS / 2 ? 0u : 65023u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t k = (uint32_t)(k0 + 2 * j);
+      w[j] = ((base + k) & 0xFFFFu) | (((base + k + 1u) & 0xFFFFu) << 16);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 2 * j;
+      w[j] = (uint32_t)aivc_laplace_cdf_u16(k, s) | ((uint32_t)aivc_laplace_cdf_u16(k + 1, s) << 16);
+    }
+  }
+  if (valid) *reinterpret_cast<uint4 *>(win + (fm.pos_off + pos) * CDF_WIN + chunk * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void laplace_bounds_batch_kernel(const float *__restrict__ sigma, const int16_t *__restrict__ q,
+                                                                   size_t npix, int c, const aivc_frame_maps *__restrict__ frames,
+                                                                   uint32_t *__restrict__ bounds) {
+  const aivc_frame_maps &fm = frames[blockIdx.y];
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (size_t)fm.n_maps * npix) return;
+  const int ch = fm.idx[pos / npix];
+  const size_t pix = pos % npix;
+  const size_t o = ((size_t)blockIdx.y * npix + pix) * c + ch;
+  const float s = sigma[o];
+  const int sym = min(max((int)q[o] + AIVC_AC_MAX_VAL, 0), AIVC_MAX_SYMBOL);
+  const uint32_t lo = aivc_laplace_cdf_u16(sym, s), hi = sym == AIVC_MAX_SYMBOL ? 0u : aivc_laplace_cdf_u16(sym + 1, s);
+  bounds[fm.pos_off + pos] = lo | (hi << 16);
+}
+
+__global__ __launch_bounds__(256) void scatter_symbols_batch_kernel(const uint16_t *__restrict__ sym, size_t npix, int c,
+                                                                    const aivc_frame_maps *__restrict__ frames,
+                                                                    int16_t *__restrict__ q, int vec) {
+  __shared__ int16_t slot[AIVC_MAX_MAPS];  // channel -> position in the frame's coded list, or -1
+  const aivc_frame_maps &fm = frames[blockIdx.y];
+  for (int i = threadIdx.x; i < AIVC_MAX_MAPS; i += blockDim.x) slot[i] = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < fm.n_maps; i += blockDim.x) slot[fm.idx[i]] = (int16_t)i;
+  __syncthreads();
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = (c + 7) / 8;
+  if (gid >= npix * groups) return;
+  const size_t pix = gid % npix;
+  const int ch0 = (int)(gid / npix) * 8;
+  const uint16_t *fs = sym + fm.pos_off;
+  int16_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = ch0 + e;
+    const int m = ch < c ? slot[ch] : -1;
+    v[e] = m < 0 ? (int16_t)0 : (int16_t)((int)fs[(size_t)m * npix + pix] - AIVC_AC_MAX_VAL);
+  }
+  int16_t *dst = q + ((size_t)blockIdx.y * npix + pix) * c + ch0;
+  if (vec) {
     uint4 o;
     o.x = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
     o.y = (uint32_t)(uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
@@ -665,6 +774,50 @@ AIVC_EXPORT int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c
   hipLaunchKernelGGL(scatter_symbols_kernel, dim3(cdiv(npix * ((c + 7) / 8), 256)), dim3(256), 0, to_stream(stream), sym, npix,
                      c, inv, q, vec);
   return check_launch("scatter_symbols");
+}
+
+AIVC_EXPORT int aivc_laplace_cdf_windows_batch(const float *sigma, int32_t n, size_t npix, int32_t c,
+                                               const aivc_frame_maps *frames, int32_t max_maps, uint16_t *win,
+                                               float *sigma_pos, aivc_stream_t stream) {
+  if (!sigma || !frames || !win || !sigma_pos || c <= 0 || c > AIVC_MAX_MAPS || n <= 0 || n > 65535 || max_maps < 0 || max_maps > c)
+    return AIVC_ERR_ARG;
+  const size_t n_pos = (size_t)max_maps * npix;
+  if (n_pos == 0) return AIVC_OK;
+  const size_t total = ((n_pos + 63) / 64) * (CDF_WIN / 8) * 64;
+  hipLaunchKernelGGL(laplace_cdf_windows_batch_kernel, dim3(cdiv(total, 256), (unsigned)n), dim3(256), 0, to_stream(stream),
+                     sigma, npix, c, frames, win, sigma_pos);
+  return check_launch("laplace_cdf_windows_batch");
+}
+
+AIVC_EXPORT int aivc_laplace_bounds_batch(const float *sigma, const int16_t *q, int32_t n, size_t npix, int32_t c,
+                                          const aivc_frame_maps *frames, int32_t max_maps, uint32_t *bounds,
+                                          aivc_stream_t stream) {
+  if (!sigma || !q || !frames || !bounds || c <= 0 || c > AIVC_MAX_MAPS || n <= 0 || n > 65535 || max_maps < 0 || max_maps > c)
+    return AIVC_ERR_ARG;
+  const size_t total = (size_t)max_maps * npix;
+  if (total == 0) return AIVC_OK;
+  hipLaunchKernelGGL(laplace_bounds_batch_kernel, dim3(cdiv(total, 256), (unsigned)n), dim3(256), 0, to_stream(stream), sigma, q,
+                     npix, c, frames, bounds);
+  return check_launch("laplace_bounds_batch");
+}
+
+AIVC_EXPORT int aivc_table_bounds_batch(const uint16_t *table, const int16_t *q, int32_t n, size_t npix, int32_t c,
+                                        uint32_t *bounds, aivc_stream_t stream) {
+  if (!table || !q || !bounds || c <= 0 || n <= 0 || n > 65535) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  hipLaunchKernelGGL(table_bounds_batch_kernel, dim3(cdiv((size_t)c * npix, 256), (unsigned)n), dim3(256), 0, to_stream(stream),
+                     table, q, npix, c, bounds);
+  return check_launch("table_bounds_batch");
+}
+
+AIVC_EXPORT int aivc_scatter_symbols_batch(const uint16_t *sym, int32_t n, size_t npix, int32_t c,
+                                           const aivc_frame_maps *frames, int16_t *q, aivc_stream_t stream) {
+  if (!q || !frames || !sym || c <= 0 || c > AIVC_MAX_MAPS || n <= 0 || n > 65535) return AIVC_ERR_ARG;
+  if (npix == 0) return AIVC_OK;
+  const int vec = (c & 7) == 0 && ((uintptr_t)q & 15) == 0;
+  hipLaunchKernelGGL(scatter_symbols_batch_kernel, dim3(cdiv(npix * ((c + 7) / 8), 256), (unsigned)n), dim3(256), 0,
+                     to_stream(stream), sym, npix, c, frames, q, vec);
+  return check_launch("scatter_symbols_batch");
 }
 
 static int check_batch(const aivc_rc_batch *b) {

@@ -527,6 +527,67 @@ def laplace_cdf_windows(sigma, maps, out=None, row_off=0):
     return out
 
 
+def frame_maps_to_device(maps_list, npix, device):
+    """device image of the aivc_frame_maps table of a frame batch (pinned staging, asynchronous copy)
+    -> (uint8 CUDA tensor [n, 272], [pos_off per frame], total coded positions)"""
+    tab, offs, total = abi.frame_maps_table(maps_list, npix)
+    host = _pinned_staging(tab.size)
+    host.numpy()[:] = tab.reshape(-1)
+    dev = torch.empty(tab.size, dtype=torch.uint8, device=device)
+    dev.copy_(host, non_blocking=True)
+    _pinned_release(host)
+    return dev, offs, total
+
+
+def laplace_cdf_windows_batch(sigma, maps_list, out, table=None):
+    """the windows + sigma of every coded position of a frame batch in ONE launch: sigma [n,h,w,c], maps_list[f] the coded
+    channels of frame f, out = (win [>= total, CDF_WIN] int16, sigma_pos [>= total]) -> ([pos_off per frame], table)"""
+    sigma = _dev(sigma, torch.float32, 'sigma')
+    n, c = sigma.shape[0], sigma.shape[-1]
+    npix = sigma.numel() // (n * c)
+    table = table or frame_maps_to_device(maps_list, npix, sigma.device)
+    dev, offs, total = table
+    win, sp = out
+    assert win.shape[0] >= total and sp.shape[0] >= total
+    mx = max((len(m) for m in maps_list), default=0)
+    if total:
+        _hbm_profiled('cdf_points:laplace_cdf_windows', total * abi.CDF_WIN,
+                      lambda: call('aivc_laplace_cdf_windows_batch', _p(sigma), n, npix, c, _p(dev), mx, _p(win), _p(sp), _stream()))
+    return offs, table
+
+
+def laplace_bounds_batch(sigma, q, maps_list):
+    """-> (bounds int32 [total], [pos_off per frame]) of a frame batch in one launch"""
+    sigma, q = _dev(sigma, torch.float32, 'sigma'), _dev(q, torch.int16, 'q')
+    n, c = sigma.shape[0], sigma.shape[-1]
+    npix = sigma.numel() // (n * c)
+    dev, offs, total = frame_maps_to_device(maps_list, npix, sigma.device)
+    bounds = torch.empty(max(total, 1), dtype=torch.int32, device=sigma.device)
+    mx = max((len(m) for m in maps_list), default=0)
+    if total:
+        call('aivc_laplace_bounds_batch', _p(sigma), _p(q), n, npix, c, _p(dev), mx, _p(bounds), _stream())
+    return bounds, offs
+
+
+def table_bounds_batch(table, q):
+    """q [n,h,w,c] -> bounds int32 [n, c * npix] (every channel of every frame, pmf mode) in one launch"""
+    q = _dev(q, torch.int16, 'q')
+    n, c = q.shape[0], q.shape[-1]
+    npix = q.numel() // (n * c)
+    bounds = torch.empty((n, c * npix), dtype=torch.int32, device=q.device)
+    call('aivc_table_bounds_batch', _p(table), _p(q), n, npix, c, _p(bounds), _stream())
+    return bounds
+
+
+def scatter_symbols_batch(sym, maps_list, n, npix, c, table=None):
+    """sym: the decoded symbols of the batch in stream order (frame f's at its pos_off) -> q int16 [n, npix, c]"""
+    dev_ = sym.device
+    table = table or frame_maps_to_device(maps_list, npix, dev_)
+    q = torch.empty((n, npix, c), dtype=torch.int16, device=dev_)
+    call('aivc_scatter_symbols_batch', _p(sym), n, npix, c, _p(table[0]), _p(q), _stream())
+    return q
+
+
 def laplace_bounds(sigma, q, maps):
     sigma, q = _dev(sigma, torch.float32, 'sigma'), _dev(q, torch.int16, 'q')
     c = sigma.shape[-1]
@@ -573,7 +634,16 @@ def range_encode(bounds_list, streams=None):
     run concurrently on them, forked from / joined back into the current stream with events."""
     n = len(bounds_list)
     dev = bounds_list[0].device
-    allb = bounds_list[0] if n == 1 else torch.cat(bounds_list)
+    # views that already sit back to back in one tensor (the batched bounds kernels) need no concatenation
+    base = bounds_list[0]._base if bounds_list[0]._base is not None else bounds_list[0]
+    pos, packed = bounds_list[0].storage_offset(), True
+    for b in bounds_list:
+        packed = packed and (b._base if b._base is not None else b) is base and b.storage_offset() == pos and b.is_contiguous()
+        pos += b.numel()
+    if packed:
+        allb = base.reshape(-1)[bounds_list[0].storage_offset():pos]
+    else:
+        allb = bounds_list[0] if n == 1 else torch.cat(bounds_list)
     in_offs, out_offs, in_off, out_off = [], [], 0, 0
     for b in bounds_list:
         cap = (16 + 3 * b.numel() + 3) // 4 * 4
@@ -612,7 +682,7 @@ def range_encode(bounds_list, streams=None):
     return out, lens, out_offs
 
 
-def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None, want_bits=False):
+def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None, want_bits=False, flat=False):
     """Decode len(payloads) independent streams concurrently (one wavefront each, <= 64 per launch).
     rows: ONE int16 CUDA tensor [n_rows, CDF_ROW] holding every stream's CDF rows; stream i starts at
     row row_offs[i] and uses one row per symbol (planes[i] == 0) or row i // planes[i] (pmf tables).
@@ -655,6 +725,8 @@ def range_decode(payloads, rows, row_offs, n_syms, planes, sigma_pos=None, want_
             call('aivc_range_decode', _p(dbytes), _p(rows), C.byref(batch), _p(sym), bp, _stream())
         else:
             call('aivc_range_decode_windows', _p(dbytes), _p(rows), _p(sigma_pos), C.byref(batch), _p(sym), bp, _stream())
+    if flat:  # the one tensor the streams' symbols sit in, back to back in stream order
+        outs = sym
     return (outs, bits) if want_bits else outs
 
 

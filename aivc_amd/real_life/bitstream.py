@@ -27,8 +27,11 @@ class PendingSection:
     """A latent of ONE frame whose symbols are known on the device but not yet range-coded.
     q / sigma are [1,h,w,c] views; `flags` is that frame's row of a batched non-zero-map tensor."""
 
-    def __init__(self, mode, q, sigma=None, table=None, flags=None, md5=b''):
+    def __init__(self, mode, q, sigma=None, table=None, flags=None, md5=b'', batch=None):
         self.mode, self.q, self.sigma, self.table, self.flags, self.md5 = mode, q, sigma, table, flags, md5
+        # (q of the whole frame batch, its sigma or None, this frame's index in it): sections of one batch get their CDF
+        # bounds from ONE launch (aivc_laplace_bounds_batch / aivc_table_bounds_batch) instead of one per frame
+        self.batch = batch
 
 
 _MD5_LINES = None
@@ -180,18 +183,50 @@ def launch_finalize(frames_sections, side_stream=None, prepared=None, fork_strea
         ctx.__enter__()
     try:
         jobs, bounds = [], []
+        # y sections: one bounds launch per frame BATCH the sections were cut from (a dependency level's latents)
+        groups = {}
         for j, (fi, si, s) in enumerate(lap):
             maps = [int(c) for c in np.nonzero(flags_h[j])[0]]
             heads[fi][si] = s.md5 + bytes([len(maps)]) + bytes(maps)
-            if maps:
-                jobs.append((fi, si))
-                bounds.append(ops.laplace_bounds(s.sigma, s.q, maps))
+            key = id(s.batch[0]) if s.batch is not None else ('single', j)
+            groups.setdefault(key, []).append((fi, si, s, maps))
+        for members in groups.values():
+            s0 = members[0][2]
+            if s0.batch is None:
+                fi, si, s, maps = members[0]
+                if maps:
+                    jobs.append((fi, si))
+                    bounds.append(ops.laplace_bounds(s.sigma, s.q, maps))
+                continue
+            q_b, sigma_b, _ = s0.batch
+            per_frame = [[] for _ in range(q_b.shape[0])]
+            for fi, si, s, maps in members:
+                per_frame[s.batch[2]] = maps
+            npix = q_b.shape[1] * q_b.shape[2]
+            allb, offs = ops.laplace_bounds_batch(sigma_b, q_b, per_frame)
+            for fi, si, s, maps in sorted(members, key=lambda m: m[2].batch[2]):
+                if maps:
+                    jobs.append((fi, si))
+                    bounds.append(allb[offs[s.batch[2]]:offs[s.batch[2]] + len(maps) * npix])
+        # z sections likewise (every channel of every frame)
+        zgroups = {}
         for fi, secs in enumerate(frames_sections):
             for si, s in enumerate(secs):
                 if s is not None and s.mode == 'pmf':
                     heads[fi][si] = s.md5
+                    key = id(s.batch[0]) if s.batch is not None else ('single', fi, si)
+                    zgroups.setdefault(key, []).append((fi, si, s))
+        for members in zgroups.values():
+            s0 = members[0][2]
+            if s0.batch is None:
+                for fi, si, s in members:
                     jobs.append((fi, si))
                     bounds.append(ops.table_bounds(s.table, s.q))
+                continue
+            zb = ops.table_bounds_batch(s0.table, s0.batch[0])
+            for fi, si, s in sorted(members, key=lambda m: m[2].batch[2]):
+                jobs.append((fi, si))
+                bounds.append(zb[s.batch[2]])
         out_h = lens_h = offs = event = None
         keep = [frames_sections, bounds]
         if jobs:
@@ -248,12 +283,13 @@ class ArithmeticCoder():
     def pend_z(self, q_z):
         """q_z [n,h,w,c] -> list of n PendingSection"""
         table = self.z_table(q_z.device)
-        return [PendingSection('pmf', q_z[i:i + 1], table=table, md5=self._md5(q_z[i:i + 1]))
+        return [PendingSection('pmf', q_z[i:i + 1], table=table, md5=self._md5(q_z[i:i + 1]), batch=(q_z, None, i))
                 for i in range(q_z.shape[0])]
 
     def pend_y(self, q_y, sigma):
         flags = ops.nonzero_flags(q_y)  # async, no sync here
-        return [PendingSection('laplace', q_y[i:i + 1], sigma=sigma[i:i + 1], flags=flags[i], md5=self._md5(q_y[i:i + 1]))
+        return [PendingSection('laplace', q_y[i:i + 1], sigma=sigma[i:i + 1], flags=flags[i], md5=self._md5(q_y[i:i + 1]),
+                               batch=(q_y, sigma, i))
                 for i in range(q_y.shape[0])]
 
     def _md5(self, q):
@@ -309,10 +345,10 @@ class ArithmeticCoder():
         are decoded concurrently."""
         payloads, sums = self._strip_md5(payloads)
         n, npix = len(payloads), h * w
-        syms, bits = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n, want_bits=True)
+        sym, bits = ops.range_decode(payloads, self.z_table(device), [0] * n, [c * npix] * n, [npix] * n, want_bits=True,
+                                     flat=True)
         self._watch('z latent', bits, [len(p) for p in payloads])
-        maps = list(range(c))
-        q = torch.stack([ops.scatter_symbols(s, npix, c, maps).view(h, w, c) for s in syms])
+        q = ops.scatter_symbols_batch(sym, [range(c)] * n, n, npix, c).view(n, h, w, c)  # one launch for the batch
         self._check_md5(q, sums, 'z latent')
         return q
 
@@ -322,24 +358,24 @@ class ArithmeticCoder():
         n, h, w, c = sigma.shape
         npix = h * w
         maps = [list(p[1:1 + p[0]]) for p in payloads]
-        row_offs, total = [], 0
-        for m in maps:
-            row_offs.append(total)
-            total += len(m) * npix
         live = [i for i in range(n) if maps[i]]
-        syms = {}
+        # ONE launch each for the batch's CDF windows and for the scatter back into [n, h, w, c] (frame f's map list and
+        # stream offset come from a device table, aivc_frame_maps); the range decoder runs one wavefront per stream
+        tab = ops.frame_maps_to_device(maps, npix, sigma.device)
+        _, row_offs, total = tab
+        sym = None
         if live:
             # 64-entry CDF windows (what the decoder's fast path reads) + sigma per position; symbols outside the
             # window make the decoder rebuild the row itself -- 128 B and 64 CDF points per symbol instead of 1040 / 514
             win, sig = _rows_workspace(total, sigma.device)
-            for i in live:
-                ops.laplace_cdf_windows(sigma[i:i + 1], maps[i], out=(win, sig), row_off=row_offs[i])
+            ops.laplace_cdf_windows_batch(sigma, maps, (win, sig), table=tab)
             coded = [payloads[i][1 + len(maps[i]):] for i in live]
-            dec, bits = ops.range_decode(coded, win, [row_offs[i] for i in live], [len(maps[i]) * npix for i in live],
-                                         [0] * len(live), sigma_pos=sig, want_bits=True)
+            sym, bits = ops.range_decode(coded, win, [row_offs[i] for i in live], [len(maps[i]) * npix for i in live],
+                                         [0] * len(live), sigma_pos=sig, want_bits=True, flat=True)
             self._watch('y latent', bits, [len(p) for p in coded])
-            syms = dict(zip(live, dec))
-        q = torch.stack([ops.scatter_symbols(syms.get(i), npix, c, maps[i]).view(h, w, c) for i in range(n)])
+        if sym is None:
+            sym = torch.zeros(1, dtype=torch.int16, device=sigma.device)
+        q = ops.scatter_symbols_batch(sym, maps, n, npix, c, table=tab).view(n, h, w, c)
         self._check_md5(q, sums, 'y latent')
         return q
 

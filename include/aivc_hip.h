@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 10
+#define AIVC_ABI_VERSION 11
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -370,6 +370,30 @@ int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *win, const f
  * all other channels 0.  (src/real_life/bitstream.py:458-466) */
 int aivc_scatter_symbols(const uint16_t *sym, size_t npix, int32_t c, const aivc_map_list *maps,
                          int16_t *q, aivc_stream_t stream);
+
+/* ---- one launch per frame BATCH for the CDF-bound / scatter kernels (the frames of a dependency level) ----------
+ * Per frame f of the batch: which y maps are coded (as aivc_map_list) and where its coded positions start in the
+ * concatenated stream-order arrays.  The table lives in DEVICE memory (272 bytes per frame: beyond kernel-argument
+ * space for a 64-frame level); sigma / q are the batch tensors [n][npix][c].  Frame f's results are bit-identical to
+ * the single-frame call with its map list, written / read at element offset pos_off. */
+typedef struct aivc_frame_maps {
+  uint64_t pos_off; /* first coded position (symbol) of frame f in bounds / win / sigma_pos / sym */
+  int32_t n_maps;
+  int32_t reserved;
+  uint8_t idx[AIVC_MAX_MAPS];
+} aivc_frame_maps;
+int aivc_laplace_cdf_windows_batch(const float *sigma, int32_t n, size_t npix, int32_t c,
+                                   const aivc_frame_maps *frames, int32_t max_maps, uint16_t *win,
+                                   float *sigma_pos, aivc_stream_t stream);
+int aivc_laplace_bounds_batch(const float *sigma, const int16_t *q, int32_t n, size_t npix, int32_t c,
+                              const aivc_frame_maps *frames, int32_t max_maps, uint32_t *bounds,
+                              aivc_stream_t stream);
+/* every channel of every frame (pmf mode): bounds[(f * c + ch) * npix + pix] */
+int aivc_table_bounds_batch(const uint16_t *table, const int16_t *q, int32_t n, size_t npix, int32_t c,
+                            uint32_t *bounds, aivc_stream_t stream);
+/* q[f][pix][frames[f].idx[m]] = sym[frames[f].pos_off + m * npix + pix] - 256, every other channel 0 */
+int aivc_scatter_symbols_batch(const uint16_t *sym, int32_t n, size_t npix, int32_t c,
+                               const aivc_frame_maps *frames, int16_t *q, aivc_stream_t stream);
 
 /* ---- quality metrics, fp64 planes [n][h][w] on the device -------------------------
  * Scratch for the three calls below, in bytes (for the largest plane they will see). */

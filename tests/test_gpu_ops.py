@@ -14,6 +14,8 @@ def T(a, dev):
 
 def eq(a_gpu, b_np):
     a = a_gpu.cpu().numpy()
+    if isinstance(b_np, torch.Tensor):
+        b_np = b_np.cpu().numpy()
     if a.dtype == np.int16 and b_np.dtype == np.uint16:
         a = a.view(np.uint16)
     if a.dtype == np.int32 and b_np.dtype == np.uint32:
@@ -549,3 +551,47 @@ def test_pack_images_bit_exact(h, w, cuda, oracle):
                 assert not got[..., 4 * i:4 * i + 4].any()
             else:
                 assert torch.equal(got[..., 4 * i:4 * i + 3], parts_t[i][..., :3]) and not got[..., 4 * i + 3].any()
+
+
+def test_frame_batch_entropy_kernels_equal_per_frame_calls(oracle, cuda):
+    """aivc_laplace_cdf_windows_batch / laplace_bounds_batch / table_bounds_batch / scatter_symbols_batch (one launch per
+    frame batch, per-frame map lists in a device table) == the single-frame entry points frame by frame, incl. frames
+    with no coded map, and == the oracle's twins"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(21)
+    n, h, w, c = 5, 7, 9, 16
+    npix = h * w
+    sig = (np.abs(rng.standard_normal((n, h, w, c))) * 2 + 0.05).astype(np.float32)
+    q = np.clip(np.rint(rng.standard_normal((n, h, w, c)) * sig), -256, 256).astype(np.int16)
+    maps = [[0, 3, 15], [], [1], list(range(c)), [2, 14]]
+    sd, qd = T(sig, cuda), T(q, cuda)
+    # bounds
+    allb, offs = ops.laplace_bounds_batch(sd, qd, maps)
+    for f, m in enumerate(maps):
+        if m:
+            eq(allb[offs[f]:offs[f] + len(m) * npix], ops.laplace_bounds(sd[f:f + 1], qd[f:f + 1], m))
+            np.testing.assert_array_equal(allb[offs[f]:offs[f] + len(m) * npix].cpu().numpy().view(np.uint32),
+                                          oracle.laplace_bounds(sig[f:f + 1], q[f:f + 1], m))
+    # windows + sigma per position
+    total = sum(len(m) for m in maps) * npix
+    win = torch.zeros((total, abi.CDF_WIN), dtype=torch.int16, device=cuda)
+    sp = torch.zeros(total, dtype=torch.float32, device=cuda)
+    offs2, tab = ops.laplace_cdf_windows_batch(sd, maps, (win, sp))
+    assert offs2 == offs
+    for f, m in enumerate(maps):
+        if m:
+            w1, s1 = ops.laplace_cdf_windows(sd[f:f + 1], m)
+            eq(win[offs[f]:offs[f] + len(m) * npix], w1)
+            eq(sp[offs[f]:offs[f] + len(m) * npix], s1)
+    # pmf bounds of every channel
+    table = T(rng.integers(0, 65535, (c, abi.CDF_ROW)).astype(np.uint16).view(np.int16), cuda)
+    zb = ops.table_bounds_batch(table, qd)
+    for f in range(n):
+        eq(zb[f], ops.table_bounds(table, qd[f:f + 1]))
+    # scatter: symbols in stream order -> [n, npix, c]
+    sym = torch.cat([(qd[f].reshape(npix, c)[:, m].T.reshape(-1).to(torch.int32) + 256).to(torch.int16) for f, m in enumerate(maps) if m])
+    back = ops.scatter_symbols_batch(sym, maps, n, npix, c, table=tab).view(n, h, w, c)
+    want = np.zeros_like(q)
+    for f, m in enumerate(maps):
+        want[f][..., m] = q[f][..., m]
+    eq(back, want)
