@@ -511,7 +511,9 @@ def main():
                                       if sharded else ('one GPU' if world == 1 else 'one clip per GPU (replicas)')),
                        'requested_frames_per_step': args.frames, 'coded_frames_per_step': coded, 'units_per_step': n_units,
                        'nonzero_y_maps': {'mofnet': active_y[0], 'codecnet': active_y[1], 'of': widths['c_y']},
-                       'parallelism': ('unit-groups x%d, level-sharded x%d' % (g, r_)) if sharded else ('single GPU' if world == 1 else 'replicas x%d' % world)},
+                       'parallelism': ('unit-groups x%d, level-sharded x%d%s' % (g, r_, ', levels narrower than the group in row bands'
+                                                                                   if fc._banded(shard, 1, args.height, args.width) else ''))
+                       if sharded else ('single GPU' if world == 1 else 'replicas x%d' % world)},
             'coded_frames_per_s': round(clips_done * coded / elapsed, 4),
             # main-stream time between events recorded after each phase was ISSUED: the decoder's entropy stage starts
             # on side streams under the encoder's last synthesis, so the two halves overlap (not comparable with the
