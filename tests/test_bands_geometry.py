@@ -66,54 +66,19 @@ def _run_ranks(R, fn):
 
 @pytest.mark.parametrize('h_y,R,seed', [(3, 2, 0), (5, 3, 1), (2, 4, 2), (9, 4, 3), (7, 8, 4), (17, 8, 5)])
 def test_banded_chain_equals_whole_map(h_y, R, seed, oracle):
-    """analysis-like chain down to the y grid, a gather, a synthesis-like chain back up (with residual / gate operands
-    and an odd top height): every rank's valid rows == the whole-map result"""
-    rng = np.random.default_rng(seed)
-    c, w = 4, 6
-    H = h_y * 4 - int(rng.integers(0, 2))  # two stride-2 stages; odd sizes included
-    x = rng.standard_normal((1, H, w, c)).astype(np.float32)
-    W = {n: (rng.standard_normal(s) * 0.3).astype(np.float32) for n, s in
-         dict(a=(c, 5, 5, c), b=(c, 3, 3, c), c=(c, 3, 3, c), d=(c, 1, 1, c), e=(c, 5, 5, c), f=(c, 3, 3, c), g=(c, 1, 1, c), s=(c, 1, 1, c)).items()}
-
-    def conv(xs, wname, mode=abi.MODE_CONV, stride=1, pad=0, res=None, mul=None, act1=0):
-        return oracle.conv2d(xs, W[wname], None, mode=mode, stride=stride, pad=pad, res=res, mul=mul, act1=act1)
-
-    # whole map
-    t1 = conv(x, 'a', stride=2, pad=2)                       # 5x5 s2
-    sk = conv(t1, 's', stride=2, pad=0)                      # 1x1 s2 unpadded skip
-    t2 = conv(conv(t1, 'b', stride=2, pad=1), 'c', pad=1, res=sk)  # 3x3 s2, 3x3 + residual -> y grid
+    """analysis-like chain down to the y grid, a gather, a synthesis-like chain back up (tests/band_chain.py; residual /
+    gate operands, odd heights, more ranks than the coarsest grid has rows): every rank's valid rows == the whole-map
+    result, bit for bit"""
+    import band_chain
+    x, wts, H = band_chain.make_case(h_y, seed)
+    t2, want = band_chain.whole(oracle, x, wts)
     assert t2.shape[1] == h_y
-    u1 = conv(t2, 'e', mode=abi.MODE_TCONV, stride=2)        # tconv 5
-    g = conv(u1, 'd', act1=abi.ACT_SIGMOID, mul=u1, res=u1)  # 1x1 gate: u1 * sigmoid(.) + u1
-    u2 = conv(g, 'f', mode=abi.MODE_TCONV, stride=2)         # tconv 3
-    want = conv(u2, 'g')
-
-    def rank(ctx):
-        ctx.set_frame(h_y, 2)
-        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-
-        def layer(xb, wname, mode=abi.MODE_CONV, stride=1, pad=0, res=None, mul=None, act1=0):
-            def launch(xs, rs, ms):
-                n = lambda t: None if t is None else np.ascontiguousarray(t.numpy())
-                return T(conv(n(xs), wname, mode, stride, pad, n(rs), n(ms), act1))
-            return ctx.conv(launch, xb, mode, W[wname].shape[1], stride, pad, c, res=res, mul=mul)
-        o0, o1 = ctx.own(2, H)
-        xb = Band(ctx, T(x[:, o0:o1]), o0, H, 2, o0, o1)  # this rank's rows of the input
-        b1 = layer(xb, 'a', stride=2, pad=2)
-        bs = layer(b1, 's', stride=2, pad=0)
-        b2 = layer(layer(b1, 'b', stride=2, pad=1), 'c', pad=1, res=bs)
-        full = ctx.gather_full(b2)
-        np.testing.assert_array_equal(full.numpy(), t2)
-        v1 = layer(ctx.full(full, 0), 'e', mode=abi.MODE_TCONV, stride=2)
-        vg = layer(v1, 'd', act1=abi.ACT_SIGMOID, mul=v1, res=v1)
-        v2 = layer(vg, 'f', mode=abi.MODE_TCONV, stride=2)
-        out = layer(v2, 'g')
-        return out.v0, out.v1, out.rows(out.v0, out.v1).numpy().copy(), dict(ctx.comm.stats)
-    res = _run_ranks(R, rank)
+    res = _run_ranks(R, lambda ctx: band_chain.banded(oracle, ctx, x, wts, h_y, H) + (dict(ctx.comm.stats),))
     covered = 0
-    for v0, v1, rows, stats in res:
+    for full, (v0, v1), rows, stats in res:
+        np.testing.assert_array_equal(full, t2)
         np.testing.assert_array_equal(rows, want[:, v0:v1])
         covered += v1 - v0
-    assert covered == want.shape[1] and res[0][0] == 0 and res[-1][1] == want.shape[1]
+    assert covered == want.shape[1] and res[0][1][0] == 0 and res[-1][1][1] == want.shape[1]
     if R > 1 and h_y >= R:
-        assert max(s['bytes_sent'] for _, _, _, s in res) > 0  # halo rows did travel
+        assert max(r[3]['bytes_sent'] for r in res) > 0  # halo rows did travel

@@ -5,8 +5,10 @@ product's."""
 import math
 import os
 import socket
+import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -297,3 +299,55 @@ def test_clip_over_unit_groups_and_levels_matches_single_process(oracle):
     for r in res:
         (u, got), = r[4].items()  # each rank holds the frames of its group's unit
         assert got == want[5 * u:5 * u + 5]
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+# ---- row bands (aivc_amd/bands.py) over REAL processes: the band engine with its torch.distributed transport
+# (DistComm: batch_isend_irecv between neighbours + all_gather inside a sub-group, host tensors under gloo) and the
+# oracle's conv as the per-slab kernel -- the CPU twin of tests/test_gpu_multi_process.py's banded cases
+def _band_worker(rank, world, port, q, h_y, seed):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), AIVC_DIST_BACKEND='gloo')
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from aivc_amd import parallel
+    from aivc_amd.bands import BandCtx, DistComm
+    from oracle import oracle as orc
+    import band_chain
+    parallel.init_process_group()
+    orc.lib()
+    pg = dist.new_group(list(range(world)))  # (the product builds its bands on a sub-group: ClipShard.bands())
+    ctx = BandCtx(DistComm(pg, list(range(world)), rank), torch.device('cpu'))
+    x, wts, H = band_chain.make_case(h_y, seed)
+    full, (v0, v1), rows = band_chain.banded(orc, ctx, x, wts, h_y, H)
+    q.put((rank, full, v0, v1, rows, dict(ctx.comm.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,h_y,seed', [(2, 5, 11), (3, 7, 12), (4, 3, 13)])
+def test_row_bands_over_gloo_processes(world, h_y, seed, oracle):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import band_chain
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, q, h_y, seed)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, wts, H = band_chain.make_case(h_y, seed)
+    t2, want = band_chain.whole(oracle, x, wts)
+    covered = 0
+    for rank, full, v0, v1, rows, stats in res:
+        np.testing.assert_array_equal(full, t2)
+        np.testing.assert_array_equal(rows, want[:, v0:v1])
+        covered += v1 - v0
+    assert covered == want.shape[1]
+    assert max(r[5]['bytes_sent'] for r in res) > 0 and all(r[5]['gathers'] == 1 for r in res)
