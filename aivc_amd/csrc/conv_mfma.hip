@@ -1204,7 +1204,10 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   // 121.5 on 256x64, 125.1 on 128x64, 125.6 on 64x64.  AIVC_TILE_RULES_R2 restores the round-2 rules below.
   static const bool r2_rules = getenv("AIVC_TILE_RULES_R2") != nullptr;
   if (!r2_rules && p.c_in % BK == 0 && (p.mode == AIVC_MODE_CONV || t)) {
-    if (co % 128 == 0) return 5;
+    // Round 4: few tiles (a single frame's 1/16-resolution layers: 8160 pixels = 128 tiles of 64x128 for 256 CUs): the 64x64
+    // tile doubles the workgroup count -- 3x3 128->128 at 68x120, batch 1: 53 -> 90 TFLOP/s, transposed 5x5 94 -> 104, equal
+    // from ~512 tiles on (tools/_ab_tiles_n4.sh at BATCH=1 / 4).  Not with a fused GDN (its tile must hold all channels).
+    if (co % 128 == 0) return (!p.gdn && blocks(64, 128) <= 512) ? 1 : 5;
     if (co <= 64 && t) return 1;
   }
   if (co <= 64 && !t && M >= 65536 && (p.c_in % BK != 0 || p.ksize == 1 || p.stride == 2)) return 6;
