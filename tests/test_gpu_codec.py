@@ -548,3 +548,31 @@ def test_stream_check_clean_and_damaged(cuda, tmp_path, capsys):
     rl_decode.decode_one_video({'decoder': rl_decode.Decoder({'full_net': model}), 'bitstream_path': str(tmp_path / 'ok.bin'),
                                 'device': str(cuda), 'out_file': ''})
     assert rl_decode.STREAM_ERRORS == [] and '[WARN]' not in capsys.readouterr().out
+
+
+@pytest.mark.parametrize('widths', [
+    {'n2': 48, 'n': 96, 'c_y': 40, 'c_short': 24, 'c_z': 20, 'n_h': 56},      # nothing a multiple of 32 / 64
+    {'n2': 192, 'n': 192, 'c_y': 192, 'c_short': 64, 'c_z': 64, 'n_h': 192},  # wider than any tile: GDN over 192 channels,
+                                                                               # output layer from 192 features, 192 y maps
+    {'n2': 12, 'n': 20, 'c_y': 12, 'c_short': 4, 'c_z': 12, 'n_h': 8}])       # channel counts that are only multiples of 4
+def test_other_model_widths_hip_equals_oracle(widths, cuda):
+    """The real models' widths are unknown (weights absent): every launch is derived from the module tree,
+    so widths the kernels have no fused / tiled special case for must take the general paths (stand-alone GDN launch,
+    non-fused 1x1 tail, generic MFMA or scalar kernel for the thin output layer) and still give the oracle's bytes and
+    frames."""
+    from aivc_amd import synth
+    from oracle import codec as ocodec
+    from oracle import spec as ospec
+    model = synth.make_model(widths, seed=17, device=cuda)
+    frames = synth.synthetic_video(80, 48, 5, seed=8)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        enc = fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_4')
+        blob = fc.assemble_video(enc)
+        dec, _, _, _ = fc.decode_video(blob, cuda)
+    assert fc.stream_errors() == []
+    ref_blob, ref_rec = ocodec.encode_video(ospec.export_model(model), frames, '1_GOP_4')
+    assert blob == ref_blob
+    for d, r in zip(dec, ref_rec):
+        for k in 'yuv':
+            np.testing.assert_array_equal(d[k][0].cpu().numpy(), r[k])
