@@ -296,3 +296,16 @@ def test_distributed_watchdog_names_the_wait(capfd, monkeypatch):
         pass
     time.sleep(0.3)
     assert '[aivc_amd.parallel]' not in capfd.readouterr().err
+
+
+def test_unit_lengths_of_a_container_with_mixed_coding_structures():
+    """decode_video_sharded places the gathered frames by every unit's OWN length (a container may mix GOP structures:
+    decode_video / decode_units accept that) -- parallel.unit_lengths reads them from the GOP records"""
+    from aivc_amd import parallel
+    from aivc_amd.real_life import cat_binary_files as container
+    from aivc_amd.real_life import header as hdr
+    frame = (0).to_bytes(4, 'big') * 2 + (1).to_bytes(4, 'big') + b'z' + (1).to_bytes(4, 'big') + b'\x00'
+    gops = [container.pack_gop(hdr.gop_header_bytes(name, 0.), [frame] * n) for name, n in (('1_GOP_2', 3), ('1_GOP_4', 5), ('LDP_2', 3))]
+    dd = {'x': (48, 80), 'y': (3, 5), 'z': (1, 2)}
+    blob = container.pack_video(hdr.video_header_bytes(dd, len(gops), 0, 10), gops)
+    assert parallel.unit_lengths(blob) == [3, 5, 3]
