@@ -255,6 +255,7 @@ def yuv420_to_444(y, u, v, c_store=4, c_off=0, out=None):
 
 
 _CONV_IMAGES_MAX = int(os.environ.get('AIVC_CONV_IMAGES_MAX', '2'))  # tuning aid: 0 disables aivc_conv_images
+_IMAGES_UNFUSED_GDN = bool(os.environ.get('AIVC_IMAGES_UNFUSED_GDN'))  # tuning aid: the first layer's GDN as a launch of its own
 
 
 class ImageStack:
@@ -301,6 +302,9 @@ def _conv_images(x, w_ohwi, bias, stride, pad, act1, act2, mul, res, algo, gdn):
     # (5.2 vs ~4.3 ms at 16 x 1080p), one and two images at par with the conv alone and without the packed tensor
     if len(x.parts) > _CONV_IMAGES_MAX:
         return None
+    if gdn is not None and _IMAGES_UNFUSED_GDN:  # tuning aid: first layer without its fused GDN + a GDN-mode launch (bit identical)
+        t = _conv_images(x, w_ohwi, bias, stride, pad, act1, act2, mul, res, algo, None)
+        return None if t is None else globals()['gdn'](t, gdn[0], gdn[1], inverse=gdn[2])
     w_ohwi = _dev(w_ohwi, torch.float32, 'weight')
     co, k, _, cw = w_ohwi.shape
     n, h, w_, c = x.shape
