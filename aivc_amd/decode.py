@@ -17,7 +17,12 @@ def main(argv=None):
     dev = resolve_device(a.cpu)
     out = a.o if a.o.endswith('.yuv') else a.o + '.yuv'
     dec = Decoder({'full_net': get_model(a.model, dev)}).eval()
-    return decode_one_video({'decoder': dec, 'bitstream_path': a.i, 'device': str(dev), 'out_file': out})
+    from aivc_amd.real_life.cat_binary_files import ContainerError
+    try:
+        return decode_one_video({'decoder': dec, 'bitstream_path': a.i, 'device': str(dev), 'out_file': out})
+    except ContainerError as e:  # a truncated / damaged file: say so and stop (exit status 2), no frames are written
+        print('[ERROR] %s is not a complete bitstream: %s' % (a.i, e))
+        raise SystemExit(2)
 
 
 if __name__ == '__main__':

@@ -54,11 +54,11 @@ def latent_md5(q_nhwc):
 
 def split_sections(frame_bytes):
     """frame bytes -> 4 payloads (bytes)."""
+    from .cat_binary_files import _take
     out, pos = [], 0
-    for _ in SECTION_NAMES:
-        n = int.from_bytes(frame_bytes[pos:pos + 4], 'big')
-        out.append(frame_bytes[pos + 4:pos + 4 + n])
-        pos += 4 + n
+    for name in SECTION_NAMES:
+        sec, pos = _take(frame_bytes, pos, 'section ' + name)  # ContainerError on a truncated frame
+        out.append(sec)
     return out
 
 

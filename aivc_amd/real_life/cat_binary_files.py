@@ -24,27 +24,45 @@ def pack_video(video_header, gops):
     return video_header + b''.join(_lp(g) for g in gops)
 
 
+class ContainerError(ValueError):
+    """the byte string is not a complete container: a length prefix points past its end (truncated / damaged file).
+    The reference reads the same prefixes with fixed-size file reads and goes on with whatever it got
+    (src/real_life/decode.py:329-426); here a short file is an error, not garbage frames."""
+
+
+def _take(blob, pos, what):
+    """the length-prefixed record at pos -> (record, position behind it)"""
+    if pos + 4 > len(blob):
+        raise ContainerError('%s: length prefix at byte %d lies beyond the end of the data (%d bytes)' % (what, pos, len(blob)))
+    n = int.from_bytes(blob[pos:pos + 4], 'big')
+    if pos + 4 + n > len(blob):
+        raise ContainerError('%s: %d bytes announced at byte %d, only %d left' % (what, n, pos, len(blob) - pos - 4))
+    return blob[pos + 4:pos + 4 + n], pos + 4 + n
+
+
 def unpack_video(blob):
     """-> (data_dim, idx_first, idx_last, [gop bytes])"""
+    if len(blob) < hdr.VIDEO_HEADER_SIZE_BYTES:
+        raise ContainerError('video header: %d bytes, need %d' % (len(blob), hdr.VIDEO_HEADER_SIZE_BYTES))
     data_dim, nb_gop, first, last = hdr.parse_video_header(blob[:hdr.VIDEO_HEADER_SIZE_BYTES])
     pos, gops = hdr.VIDEO_HEADER_SIZE_BYTES, []
-    for _ in range(nb_gop):
-        n = int.from_bytes(blob[pos:pos + 4], 'big')
-        gops.append(blob[pos + 4:pos + 4 + n])
-        pos += 4 + n
+    for g in range(nb_gop):
+        rec, pos = _take(blob, pos, 'GOP record %d of %d' % (g, nb_gop))
+        gops.append(rec)
     return data_dim, first, last, gops
 
 
 def unpack_gop(blob):
     """-> (GOP_struct_name, idx_rate, [frame bytes in display order])"""
+    if len(blob) < hdr.GOP_HEADER_SIZE_BYTES:
+        raise ContainerError('GOP header: %d bytes, need %d' % (len(blob), hdr.GOP_HEADER_SIZE_BYTES))
     name, idx_rate = hdr.parse_gop_header(blob[:hdr.GOP_HEADER_SIZE_BYTES])
     from ..func_util.GOP_structure import generate_gop_struct
     n_frames = len(generate_gop_struct(name))
     pos, frames = hdr.GOP_HEADER_SIZE_BYTES, []
-    for _ in range(n_frames):
-        n = int.from_bytes(blob[pos:pos + 4], 'big')
-        frames.append(blob[pos + 4:pos + 4 + n])
-        pos += 4 + n
+    for i in range(n_frames):
+        rec, pos = _take(blob, pos, 'frame %d of %d (%s)' % (i, n_frames, name))
+        frames.append(rec)
     return name, idx_rate, frames
 
 

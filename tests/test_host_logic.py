@@ -309,3 +309,23 @@ def test_unit_lengths_of_a_container_with_mixed_coding_structures():
     dd = {'x': (48, 80), 'y': (3, 5), 'z': (1, 2)}
     blob = container.pack_video(hdr.video_header_bytes(dd, len(gops), 0, 10), gops)
     assert parallel.unit_lengths(blob) == [3, 5, 3]
+
+
+def test_truncated_container_is_an_error_not_garbage():
+    """every length prefix of the container is checked against the data at hand: a short file raises ContainerError naming
+    the record (the reference's fixed-size reads would carry on with what they got, src/real_life/decode.py:329-426)"""
+    from aivc_amd.real_life import cat_binary_files as container
+    from aivc_amd.real_life import header as hdr
+    from aivc_amd.real_life.bitstream import split_sections
+    frame = (0).to_bytes(4, 'big') * 2 + (3).to_bytes(4, 'big') + b'abc' + (1).to_bytes(4, 'big') + b'\x00'
+    gop = container.pack_gop(hdr.gop_header_bytes('1_GOP_2', 0.), [frame] * 3)
+    blob = container.pack_video(hdr.video_header_bytes({'x': (48, 80), 'y': (3, 5), 'z': (1, 2)}, 2, 0, 5), [gop, gop])
+    assert len(container.unpack_video(blob)[3]) == 2 and len(container.unpack_gop(gop)[2]) == 3
+    for cut in (5, 17, 20, len(blob) - 1, len(blob) - len(gop) + 3):
+        with pytest.raises(container.ContainerError):
+            container.unpack_video(blob[:cut])
+    with pytest.raises(container.ContainerError, match='frame 2 of 3'):
+        container.unpack_gop(gop[:-4])
+    with pytest.raises(container.ContainerError, match='codecnet_y'):
+        split_sections(frame[:-1])
+    assert split_sections(frame) == [b'', b'', b'abc', b'\x00']
