@@ -52,12 +52,15 @@ def latent_md5(q_nhwc):
     return hashlib.md5(b''.join([lines[x + off] for x in v.tolist()])).hexdigest().encode()
 
 
-def split_sections(frame_bytes):
-    """frame bytes -> 4 payloads (bytes)."""
+def split_sections(frame_bytes, upto=len(SECTION_NAMES)):
+    """frame bytes -> the payloads of its first `upto` sections (bytes).  The path API appends the sections of a frame to
+    its file one by one and reads a section back before the later ones exist (src/real_life/bitstream.py:333-350, 352-425):
+    it asks for the sections up to the one it needs; whole frames are parsed in full, a length prefix running past the
+    data is a ContainerError."""
     from .cat_binary_files import _take
     out, pos = [], 0
-    for name in SECTION_NAMES:
-        sec, pos = _take(frame_bytes, pos, 'section ' + name)  # ContainerError on a truncated frame
+    for name in SECTION_NAMES[:upto]:
+        sec, pos = _take(frame_bytes, pos, 'section ' + name)
         out.append(sec)
     return out
 
@@ -462,7 +465,7 @@ class ArithmeticCoder():
         if not path.endswith(BITSTREAM_SUFFIX):
             path += BITSTREAM_SUFFIX
         with open(path, 'rb') as f:
-            payload = split_sections(f.read())[SECTION_NAMES.index(latent_name)]
+            payload = split_sections(f.read(), SECTION_NAMES.index(latent_name) + 1)[-1]
         keep, self.flag_md5sum = self.flag_md5sum, bool(get_value('flag_md5sum', param, default))
         try:
             n_err = len(self.md5_errors)
