@@ -329,3 +329,5 @@ def test_truncated_container_is_an_error_not_garbage():
     with pytest.raises(container.ContainerError, match='codecnet_y'):
         split_sections(frame[:-1])
     assert split_sections(frame) == [b'', b'', b'abc', b'\x00']
+    # the path API reads a section back while the later ones are not written yet (src/real_life/bitstream.py:333-350)
+    assert split_sections(frame[:-5], upto=3) == [b'', b'', b'abc']
