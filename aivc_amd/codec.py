@@ -185,8 +185,8 @@ class FrameCodec:
         """A dependency level with fewer frames than the group has ranks can be coded frame by frame in row bands over
         all of them (configs[4]: the 1-, 1-, 1-, 2-, 4-frame levels of a single 4K unit on 8 GPUs).  It pays when a
         band's kernels plus ~70 halo exchanges per frame beat one rank doing the frame alone
-        (profiles/r04_band_stats_*.json: per-rank kernel time 8.5 vs 28.5 ms for a 4K B frame on 8 ranks, but 7.7 vs
-        9.1 ms at 1080p on 2): by default from 4 ranks per group on, or from 2 for frames of >= 6 Mpixel.
+        (profiles/r04_band_stats_*.json: per-rank kernel time 8.0 vs 29.0 ms for a 4K B frame on 8 ranks, 5.8 vs 9.0 ms at
+        1080p on 4, but 7.7 vs 9.1 ms at 1080p on 2): by default from 4 ranks per group on, or from 2 for frames of >= 6 Mpixel.
         AIVC_BAND_LEVELS=1 / 0 forces it on / off (every rank must see the same value)."""
         if shard is None or shard.R <= 1 or n_frames >= shard.R or not getattr(shard, 'band_levels', True):
             return False

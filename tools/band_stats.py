@@ -60,11 +60,30 @@ def kernel_ms(fn):
     return tot / 1e3
 
 
+def kernel_table(fn, top=14):
+    """{kernel name (short): (calls, ms)} of fn()'s GPU kernels, largest first"""
+    import collections
+    from torch.profiler import ProfilerActivity, profile
+    fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.device_type is not None and 'cuda' in str(e.device_type).lower():
+            k = e.name.split('(')[0].replace('void ', '').replace('aivc::', '')[:70]
+            per[k][0] += 1
+            per[k][1] += (e.device_time if hasattr(e, 'device_time') else e.cuda_time) / 1e3
+    return sorted(per.items(), key=lambda kv: -kv[1][1])[:top]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--width', type=int, default=3840)
     ap.add_argument('--height', type=int, default=2160)
     ap.add_argument('--ranks', type=int, default=8)
+    ap.add_argument('--detail', action='store_true', help='per-kernel tables of the B frame, single rank vs all bands (stderr)')
     a = ap.parse_args()
     from aivc_amd import synth
     from aivc_amd.codec import FrameCodec
@@ -96,6 +115,14 @@ def main():
                 'p2p_bytes_sent_per_rank_max': max(s['bytes_sent'] for s in st),
                 'all_gathers_per_rank': max(s['gathers'] for s in st),
                 'all_gather_bytes_received_per_rank': max(s['bytes_gathered'] for s in st)}
+    if a.detail:
+        with torch.no_grad():
+            cur, p, n = frames[1], prev, nxt
+            for title, fn in (('single rank', lambda: fc.encode_batch([cur], [p], [n], FRAME_B)),
+                              ('all %d bands' % a.ranks, lambda: run_ranks(a.ranks, lambda b: fc.encode_banded(cur, p, n, FRAME_B, 0., b)))):
+                sys.stderr.write('--- B frame, %s\n' % title)
+                for k, (c, ms) in kernel_table(fn):
+                    sys.stderr.write('%6d x %8.3f ms  %s\n' % (c, ms, k))
     print(json.dumps(out, indent=1))
 
 
