@@ -49,16 +49,19 @@ def main(argv=None):
                   '-o', a.bitstream_out] + common)
     banner(('*' * 80).center(120))
     banner('Starting decoding'.center(120))
-    dec_cli.main(['-i', a.bitstream_out, '-o', a.o] + common)
+    status = dec_cli.main(['-i', a.bitstream_out, '-o', a.o] + common)
     from aivc_amd import parallel
     if parallel.rank_world()[0] != 0:  # multi-rank job: rank 0 evaluates
-        return
+        return status
     print(('*' * 80).center(120))
     print('Starting evaluation'.center(120))
     eval_cli.main(['--raw', a.i, '--compressed', a.o, '--bitstream', a.bitstream_out, '--start_frame', str(a.start_frame)])
+    return status  # 3: decoded and evaluated, but the stream did not decode cleanly (real_life/decode.py)
+
+
+def cli():
+    raise SystemExit(main())
 
 
 if __name__ == '__main__':
-    main()
-    from aivc_amd.real_life.decode import STREAM_ERRORS
-    raise SystemExit(3 if STREAM_ERRORS else 0)
+    cli()

@@ -36,12 +36,14 @@ class FrameCodec:
     measured 2.3 % faster than 8 at 1080p -- fewer, larger launches: less drain / ramp time between the
     ~12 k stream-ordered kernels of a step -- 32 adds 0.4 %)."""
 
-    def __init__(self, full_net, max_batch=16, entropy_chunk=64, entropy_streams=8, entropy_lookahead=2,
+    def __init__(self, full_net, max_batch=16, entropy_chunk=64, entropy_streams=8, entropy_lookahead=None,
                  flag_md5sum=False):
         self.net = full_net
         self.entropy_chunk = entropy_chunk
         self.entropy_streams = max(2, entropy_streams)  # decoder: concurrent range-coder chains
-        self.entropy_lookahead = max(1, entropy_lookahead)  # ... issued this many dependency levels ahead
+        # ... issued this many dependency levels ahead of the synthesis; None / 0: the whole video up front (when its
+        # CDF windows fit in memory, _entropy_budget)
+        self.entropy_lookahead = max(1, entropy_lookahead) if entropy_lookahead else None
         self.mof = full_net.mode_net.mode_net
         self.cod = full_net.codec_net.codec_net
         self.max_batch = max_batch
@@ -288,6 +290,32 @@ class FrameCodec:
             ac.md5_errors = []
         return out
 
+    @staticmethod
+    def _entropy_bytes(parsed, members, data_dim):
+        """device bytes the entropy stage of these units holds when all of it is issued at once: per coded y symbol the
+        64-entry CDF window + sigma (132 B, real_life/bitstream.py _rows_workspace) + the symbol, per frame the
+        hyperprior's activations and latents (bounded by 64 floats per y position per network).  The coded map counts
+        are in the sections' first byte."""
+        h_y, w_y = data_dim['y']
+        npix = h_y * w_y
+        total = 0
+        for i in members:
+            for fb in parsed[i][2]:
+                secs = split_sections(fb)
+                for sy in (secs[1], secs[3]):
+                    if sy:
+                        total += sy[0] * npix * 134 + npix * 4 * 640
+        return total
+
+    @staticmethod
+    def _entropy_budget(device):
+        """a quarter of the free device memory (AIVC_ENTROPY_BUDGET_GB overrides)"""
+        gb = _os.environ.get('AIVC_ENTROPY_BUDGET_GB')
+        if gb:
+            return int(float(gb) * 2 ** 30)
+        free, _ = torch.cuda.mem_get_info(device)
+        return free // 4
+
     def _param_stamp(self):
         """changes whenever a parameter / buffer of the model is modified in place, replaced or moved"""
         ts = getattr(self, '_param_list', None)
@@ -426,28 +454,46 @@ class FrameCodec:
             lat, ready = {}, {}
             rr = [0]
 
+            def level_items(level, ftype):
+                items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
+                if shard is not None and not self._banded(shard, len(members) * len(level), *data_dim['x']):
+                    items = shard.mine(items)  # (a banded level's latents are decoded by every rank: no exchange)
+                return items
+
+            def issue_items(ftype, items):
+                for s0 in range(0, len(items), self.entropy_chunk):
+                    chunk = items[s0:s0 + self.entropy_chunk]
+                    pair = [sides[(rr[0] + k) % len(sides)] for k in range(2)]
+                    rr[0] += 2
+                    yh, evs = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype,
+                                                  data_dim, idx_rate, device, streams=pair)
+                    for v in yh.values():
+                        if v is not None:
+                            v.record_stream(main)
+                    for j, it in enumerate(chunk):
+                        lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
+                        ready[it] = evs
+
             def issue_entropy(level):
                 for ftype in sorted({gop[f]['type'] for f in level}):
-                    items = [(i, f) for i in members for f in level if gop[f]['type'] == ftype]
-                    if shard is not None and not self._banded(shard, len(members) * len(level), *data_dim['x']):
-                        items = shard.mine(items)  # (a banded level's latents are decoded by every rank: no exchange)
-                    for s0 in range(0, len(items), self.entropy_chunk):
-                        chunk = items[s0:s0 + self.entropy_chunk]
-                        pair = [sides[(rr[0] + k) % len(sides)] for k in range(2)]
-                        rr[0] += 2
-                        yh, evs = self.entropy_decode([parsed[i][2][frame_index(f)] for i, f in chunk], ftype,
-                                                      data_dim, idx_rate, device, streams=pair)
-                        for v in yh.values():
-                            if v is not None:
-                                v.record_stream(main)
-                        for j, it in enumerate(chunk):
-                            lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
-                            ready[it] = evs
+                    issue_items(ftype, level_items(level, ftype))
 
             rec = {i: {} for i in members}
             ahead = self.entropy_lookahead
-            for li in range(min(ahead, len(levels))):
-                issue_entropy(levels[li])
+            if ahead is None and self._entropy_bytes(parsed, members, data_dim) > self._entropy_budget(device):
+                ahead = 2  # the windows of the whole group do not fit beside the activations: level by level
+            if ahead is None:
+                # the WHOLE group's entropy stage up front, frames of one type from all dependency levels in the same
+                # launches (level-major order, so the first chunk holds the frames the synthesis needs first): every
+                # serial stream of the video is then in flight at once -- what bounds the entropy stage is its longest
+                # stream, not the number of levels times it (at high rate a 4K y stream decodes for > 0.3 s, and level
+                # by level the synthesis of every level waited for that again)
+                for ftype in sorted({gop[f]['type'] for f in names}):
+                    issue_items(ftype, [it for level in levels for it in level_items(level, ftype)])
+                ahead = len(levels)
+            else:
+                for li in range(min(ahead, len(levels))):
+                    issue_entropy(levels[li])
             for li, level in enumerate(levels):
                 if li + ahead < len(levels):
                     issue_entropy(levels[li + ahead])

@@ -19,13 +19,24 @@ def main(argv=None):
     dec = Decoder({'full_net': get_model(a.model, dev)}).eval()
     from aivc_amd.real_life.cat_binary_files import ContainerError
     try:
-        return decode_one_video({'decoder': dec, 'bitstream_path': a.i, 'device': str(dev), 'out_file': out})
+        decode_one_video({'decoder': dec, 'bitstream_path': a.i, 'device': str(dev), 'out_file': out})
     except ContainerError as e:  # a truncated / damaged file: say so and stop (exit status 2), no frames are written
         print('[ERROR] %s is not a complete bitstream: %s' % (a.i, e))
         raise SystemExit(2)
+    return exit_status()
+
+
+def exit_status():
+    """0, or 3 when the frames were written but some section did not decode cleanly ON ANY RANK (every rank records
+    the sections it decoded; the counts are summed over the job so that rank 0's status speaks for all of them)"""
+    from aivc_amd.real_life.decode import stream_error_count
+    return 3 if stream_error_count() else 0
+
+
+def cli():
+    """console-script entry point: the process exit status is main()'s"""
+    raise SystemExit(main())
 
 
 if __name__ == '__main__':
-    main()
-    from aivc_amd.real_life.decode import STREAM_ERRORS
-    raise SystemExit(3 if STREAM_ERRORS else 0)  # the frames were written, but the stream did not decode cleanly
+    cli()

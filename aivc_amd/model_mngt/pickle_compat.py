@@ -7,6 +7,7 @@ snapshot, so their real dotted paths are unknown until a real pic
 first tries the dotted path as written and then falls back to a lookup by CLASS NAME over every class this package
 defines, and `pickle_globals()` lists what a file asks for without unpickling anything (tools/inspect_pickle.py).
 Names that resolve neither way are reported all at once, before the load starts."""
+import functools
 import importlib
 import io
 import pickle
@@ -70,6 +71,8 @@ def pickle_globals(path_or_bytes):
 
 
 _BY_NAME = None
+# top-level packages of the reference tree (src/): the only module paths whose classes may be bound by name
+_REFERENCE_TOPS = ('models', 'layers', 'func_util', 'real_life', 'model_mngt', 'clic21', 'format_conversion', '__main__')
 
 
 def classes_by_name():
@@ -99,8 +102,15 @@ def resolve(module, name, log=None):
         return pickle.Unpickler(io.BytesIO(b'')).find_class(module, name)
     except (ImportError, AttributeError):
         pass
-    top = module.split('.')[0]
-    if top not in ('torch', 'numpy', 'collections', 'builtins', '_codecs', 'copyreg'):
+    if '.' in name:  # a protocol-4 qualified name ('Outer.Inner'): a bare Unpickler is protocol 0 and does not split it
+        try:
+            return functools.reduce(getattr, name.split('.'), importlib.import_module(module))
+        except (ImportError, AttributeError):
+            pass
+    # by class NAME: only for paths under the reference's own top-level packages (the missing `models` package and
+    # whatever upstream called its siblings / a 'src.' prefix) -- an unknown third-party module never binds to a local class
+    parts = module.split('.')
+    if parts[0] in _REFERENCE_TOPS or (parts[0] == 'src' and len(parts) > 1 and parts[1] in _REFERENCE_TOPS):
         cls = classes_by_name().get(name.split('.')[-1])
         if cls is not None:
             if log is not None:

@@ -88,10 +88,12 @@ def _rows_workspace(n_rows, device):
 _PIN_POOL = {}
 
 
-def _pinned(n, dtype):
+def _pinned(n, dtype, floor=1 << 16):
     """pinned host staging buffer from a small free-list (hipHostMalloc per level is slow); the
-    buffer goes back to the pool when its EntropyJob has been collected"""
-    key = (dtype, max(1 << 16, 1 << (int(n) - 1).bit_length()))
+    buffer goes back to the pool when its EntropyJob has been collected.  `floor`: smallest buffer handed out
+    (entries): the big default keeps the byte / flag buffers of a level in ONE size class, the 4-byte-per-stream
+    counts of the length check ask for 64"""
+    key = (dtype, max(int(floor), 1 << (max(int(n), 1) - 1).bit_length()))
     lst = _PIN_POOL.setdefault(key, [])
     t = lst.pop() if lst else torch.empty(key[1], dtype=dtype, pin_memory=True)
     return t[:n]
@@ -266,6 +268,7 @@ class ArithmeticCoder():
         # of every range-decode launch since the last stream_errors() call
         self.flag_check_lengths = True
         self._length_checks = []
+        self._length_errors = []  # mismatches found while draining completed checks (see _watch)
         self.AC_MAX_VAL = get_value('AC_MAX_VAL', param, default)
         if self.AC_MAX_VAL != abi.AC_MAX_VAL:
             raise NotImplementedError('the kernels are built for AC_MAX_VAL = %d' % abi.AC_MAX_VAL)
@@ -314,14 +317,58 @@ class ArithmeticCoder():
                 print('\t%s frame %d of the batch' % (what, i))
                 print('-' * 80)
 
+    MAX_PENDING_CHECKS = 4096
+
+    def __getstate__(self):
+        """the queue of pending length checks holds HIP events and pinned buffers: not part of a saved model
+        (torch.save(model) after a decode)"""
+        d = dict(self.__dict__)
+        d['_length_checks'], d['_length_errors'] = [], []
+        return d
+
+    def _judge(self, entry, wait):
+        """one queued check -> its mismatches (None if its decode has not finished and wait is False); the pinned
+        counts go back to the pool"""
+        what, host, ev, lens, _ = entry
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return None
+        bad = []
+        for i, (b, ln) in enumerate(zip(host.numpy().tolist(), lens)):
+            if (int(b) + 2 + 7) // 8 != ln:
+                bad.append((what, i, ln, (int(b) + 2 + 7) // 8))
+        _unpin(host)
+        return bad
+
+    def _drain(self, wait=False):
+        """judge the checks whose decode has completed (oldest first, stops at the first one still running unless
+        `wait`): a process that never calls stream_errors() -- a service, bench.py's timed loop -- holds a handful of
+        64-entry pinned buffers, not one per decode launch since it started"""
+        q = self._length_checks
+        k = 0
+        while k < len(q):
+            bad = self._judge(q[k], wait)
+            if bad is None:
+                break
+            self._length_errors += bad
+            k += 1
+        del q[:k]
+        if len(self._length_errors) > 65536:  # nobody reads them: keep the newest
+            del self._length_errors[:32768]
+
     def _watch(self, what, bits, lens):
         """queue the check `len(payload) == (bits + 2 + 7) // 8` of a decode launch (include/aivc_hip.h,
-        aivc_range_decode): an async copy of 4 bytes per stream + an event on the decoding stream, no host wait"""
+        aivc_range_decode): an async copy of 4 bytes per stream + an event on the decoding stream, no host wait.
+        Completed checks are judged on the way (ev.query()), so the queue stays as short as the decodes in flight."""
         if not self.flag_check_lengths or bits is None:
             return
-        if len(self._length_checks) >= 65536:  # nobody is collecting (a long-running service): keep the newest
-            del self._length_checks[:32768]
-        host = _pinned(bits.numel(), torch.int32)
+        self._drain()
+        if len(self._length_checks) >= self.MAX_PENDING_CHECKS:  # the GPU is that far behind: wait for the oldest half
+            for e in self._length_checks[:self.MAX_PENDING_CHECKS // 2]:
+                self._length_errors += self._judge(e, True)
+            del self._length_checks[:self.MAX_PENDING_CHECKS // 2]
+        host = _pinned(bits.numel(), torch.int32, floor=64)
         host.copy_(bits, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -333,14 +380,8 @@ class ArithmeticCoder():
         CDFs it was written with (another implementation's sigma, a damaged file, a wrong model): the symbols of such
         a stream are garbage from the first differing bound on, and neither torchac nor the format says so.  Waits
         for the decodes concerned."""
-        bad = []
-        for what, host, ev, lens, _ in self._length_checks:
-            ev.synchronize()
-            for i, (b, ln) in enumerate(zip(host.numpy().tolist(), lens)):
-                if (int(b) + 2 + 7) // 8 != ln:
-                    bad.append((what, i, ln, (int(b) + 2 + 7) // 8))
-            _unpin(host)
-        self._length_checks = []
+        self._drain(wait=True)
+        bad, self._length_errors = self._length_errors, []
         return bad
 
     def decode_z(self, payloads, h, w, c, device):
@@ -355,12 +396,30 @@ class ArithmeticCoder():
         self._check_md5(q, sums, 'z latent')
         return q
 
+    @staticmethod
+    def _parse_maps(payload, c, index=0):
+        """[n_maps 1 B][map index 1 B each] at the head of a y payload (src/real_life/bitstream.py:426-447) -> list of
+        map indices.  The bytes come from the file: they are checked HERE, on the host, before they reach the device
+        table the batched kernels index sigma with (aivc_frame_maps cannot validate a device table; the per-frame
+        entry points answer AIVC_ERR_ARG to the same input, csrc/entropy.hip check_maps)."""
+        from .cat_binary_files import ContainerError
+        if len(payload) < 1:
+            raise ContainerError('y section of frame %d of the batch is empty (no map count)' % index)
+        n_maps = payload[0]
+        if n_maps > c or n_maps > abi.MAX_MAPS or len(payload) < 1 + n_maps:
+            raise ContainerError('y section of frame %d of the batch announces %d feature maps (latent has %d, '
+                                 'section holds %d bytes)' % (index, n_maps, c, len(payload)))
+        m = list(payload[1:1 + n_maps])
+        if any(i >= c for i in m):
+            raise ContainerError('y section of frame %d of the batch lists feature map %d of %d' % (index, max(m), c))
+        return m
+
     def decode_y(self, payloads, sigma):
         """list of n payloads + sigma [n,h,w,c] -> q_y int16 [n,h,w,c] (zero maps restored)."""
         payloads, sums = self._strip_md5(payloads)
         n, h, w, c = sigma.shape
         npix = h * w
-        maps = [list(p[1:1 + p[0]]) for p in payloads]
+        maps = [self._parse_maps(p, c, i) for i, p in enumerate(payloads)]
         live = [i for i in range(n) if maps[i]]
         # ONE launch each for the batch's CDF windows and for the scatter back into [n, h, w, c] (frame f's map list and
         # stream offset come from a device table, aivc_frame_maps); the range decoder runs one wavefront per stream

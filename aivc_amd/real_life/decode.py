@@ -111,7 +111,13 @@ def decode_one_video(param):
             frames, data_dim, first, last = fc.decode_video(blob, dev)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    report_stream_errors(fc, path)  # (every rank reports the sections IT decoded)
+    errs = report_stream_errors(fc, path)  # (every rank reports the sections IT decoded)
+    _JOB_ERRORS[0] = len(errs)
+    if world > 1:  # ... and the job's total reaches every rank: the exit status of rank 0 speaks for all of them
+        import torch.distributed as dist
+        cnt = torch.tensor([len(errs)], dtype=torch.int64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(cnt)
+        _JOB_ERRORS[0] = int(cnt.item())
     if rank != 0:
         dist_barrier_after_write(world)
         return None
@@ -128,7 +134,12 @@ def decode_one_video(param):
     return frames
 
 
-STREAM_ERRORS = []  # what the last decode_one_video found (the CLI's exit status)
+STREAM_ERRORS = []  # what the last decode_one_video found on THIS rank
+_JOB_ERRORS = [0]   # ... and how many sections failed over all ranks of the job (the CLI's exit status)
+
+
+def stream_error_count():
+    return max(_JOB_ERRORS[0], len(STREAM_ERRORS))
 
 
 def report_stream_errors(frame_codec, path=''):

@@ -98,12 +98,14 @@ def gpu_synthetic_unit(width, height, n_frames, t0, device, seed):
     return out
 
 
-def cpu_baseline(width, height, model, fc, dev):
-    """CPU legs on this box's host cores, on an I + P + B triple (`1_GOP_2`) of the same synthetic pattern, encode and
-    decode timed separately (the reference cannot run: its model sources, weights and torchac are absent):
+def cpu_baseline(width, height, model, fc, dev, gop_name='1_GOP_32', unit_frames=33):
+    """CPU legs on this box's host cores, encode and decode timed separately (the reference cannot run: its model
+    sources, weights and torchac are absent):
       * `value`: the oracle with its transforms on torch-CPU (oracle/torch_cpu.py: F.conv2d / conv_transpose2d /
-        GDN as the reference's --cpu path runs them, src/encode.py:85-93), all host threads, full-size frames;
-        `one_core`: the same on one thread at 1/16 of the area, scaled by the pixel ratio;
+        GDN as the reference's --cpu path runs them, src/encode.py:85-93) on ONE FULL INTRA-PERIOD UNIT of the
+        bench's coding structure at full frame size ("a reduced frame count, >= 1 full
+        intra-period unit"; 33 frames of `1_GOP_32` at 1080p take ~90 s), thread count swept beforehand;
+        `one_core`: an I + P + B triple (`1_GOP_2`) at full frame size on one thread;
       * `fmaf_oracle`: the parity checker itself (fixed-order fmaf chains, OpenMP) on the same full-size triple --
         the GPU codes the SAME frames with the same default-width model and bytes + reconstructions must be
         equal (`parity_checked`).  It is the checker, not a representative CPU implementation (~1 % of host peak)."""
@@ -142,19 +144,30 @@ def cpu_baseline(width, height, model, fc, dev):
             if e_ + d_ > 4 * min(sweep.values()):
                 break  # (counts are tried in ascending order: past the optimum it only gets worse)
     best = min(sweep, key=sweep.get)
-    enc_s, dec_s, closed, nbytes = timed(frames, best)
-    out = {'value': round(3.0 / (enc_s + dec_s), 5), 'unit': 'frames/s', 'cores': best, 'host_threads': cores, 'kind': 'port',
-           'encode_fps': round(3.0 / enc_s, 5), 'decode_fps': round(3.0 / dec_s, 5), 'closed_loop': bool(closed),
-           'thread_sweep_s': {str(k): v for k, v in sweep.items()},
+    # the timed sample: one whole unit of the bench's structure (AIVC_CPU_BASELINE_FRAMES trims it for quick runs)
+    n_unit = int(os.environ.get('AIVC_CPU_BASELINE_FRAMES', unit_frames))
+    unit_gop = gop_name if n_unit == unit_frames else '1_GOP_%d' % (n_unit - 1)
+    unit = synth.synthetic_video(width, height, n_unit, seed=11)
+    with torch_cpu.torch_convs(best):
+        t0 = time.time()
+        blob_u, recs_u = ocodec.encode_video(spec, unit, unit_gop)
+        t1 = time.time()
+        dec_u = ocodec.decode_video(spec, blob_u)
+        t2 = time.time()
+    enc_s, dec_s, nbytes = t1 - t0, t2 - t1, len(blob_u)
+    closed = all(np.array_equal(d[k], r[k]) for d, r in zip(dec_u, recs_u) for k in 'yuv')
+    del dec_u, recs_u
+    out = {'value': round(n_unit / (enc_s + dec_s), 5), 'unit': 'frames/s', 'cores': best, 'host_threads': cores, 'kind': 'port',
+           'encode_fps': round(n_unit / enc_s, 5), 'decode_fps': round(n_unit / dec_s, 5), 'closed_loop': bool(closed),
+           'frames': n_unit, 'thread_sweep_s': {str(k): v for k, v in sweep.items()},
            'sample': 'oracle with torch-CPU transforms (F.conv2d / conv_transpose2d / GDN, torch.set_num_threads(%d): the fastest of '
-                     'the counts swept on a %dx%d triple, host has %d) on 3 frames I+P+B (1_GOP_2) at %dx%d: encode %.1f s, '
-                     'decode %.1f s (%d bytes)' % (best, w1, h1, cores, width, height, enc_s, dec_s, nbytes)}
-    e1, d1, c1, _ = timed(small, 1)
-    s1 = (width * height) / float(w1 * h1)
-    out['one_core'] = {'value': round(3.0 / (e1 + d1) / s1, 6), 'encode_fps': round(3.0 / e1 / s1, 6),
-                       'decode_fps': round(3.0 / d1 / s1, 6), 'cores': 1, 'closed_loop': bool(c1),
-                       'sample': 'same triple at %dx%d on 1 thread: encode %.1f s, decode %.1f s; fps divided by %.1f (pixel ratio)'
-                                 % (w1, h1, e1, d1, s1)}
+                     'the counts swept on a %dx%d triple, host has %d) on %d frames = one full intra-period unit of %s at %dx%d: '
+                     'encode %.1f s, decode %.1f s (%d bytes)' % (best, w1, h1, cores, n_unit, unit_gop, width, height, enc_s, dec_s, nbytes)}
+    e1, d1, c1, _ = timed(frames, 1)
+    out['one_core'] = {'value': round(3.0 / (e1 + d1), 6), 'encode_fps': round(3.0 / e1, 6),
+                       'decode_fps': round(3.0 / d1, 6), 'cores': 1, 'closed_loop': bool(c1), 'frames': 3,
+                       'sample': '3 frames I+P+B (1_GOP_2) at %dx%d on 1 thread: encode %.1f s, decode %.1f s'
+                                 % (width, height, e1, d1)}
     # ---- the parity checker on the same full-size frames, and the HIP product path against it
     x = np.random.default_rng(0).standard_normal((1, 135, 240, 128), dtype=np.float32)
     w = np.random.default_rng(1).standard_normal((128, 3, 3, 128), dtype=np.float32) * 0.03
@@ -235,7 +248,9 @@ def main():
                     help='auto = strong (one clip over all GPUs) when N > 1')
     ap.add_argument('--max-batch', type=int, default=64, help='frames of one dependency level per launch (64 = the widest level of the clip in one batch: +0.9 %% over 16, same-box A/B)')
     ap.add_argument('--entropy-streams', type=int, default=8, help='decoder: concurrent range-coder chains')
-    ap.add_argument('--entropy-lookahead', type=int, default=2, help='decoder: dependency levels of entropy decoding issued ahead')
+    ap.add_argument('--entropy-lookahead', type=int, default=0, help='decoder: dependency levels of entropy decoding issued ahead (0: the whole clip up front)')
+    ap.add_argument('--no-high-rate', action='store_true', help='skip the high-rate operating point (every y feature map coded) measured after the headline run')
+    ap.add_argument('--high-rate-steps', type=int, default=3)
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -372,6 +387,10 @@ def main():
         raise SystemExit('bench.py: sharded bitstream differs from the single-rank bitstream')
     elapsed = timed_run(shard, args.warmup)
     main_stats = dict(stats)
+    clips_done_for_hr = args.steps * args.frames
+    # every range-decode launch of the run left its bit count behind (real_life/bitstream.py): judged now, outside the
+    # timed region -- a section that did not decode to where its payload ends would make closed_loop_ok meaningless
+    stream_errors = len(fc.stream_errors())
 
     # ---- the other scaling mode, reported next to the headline (N > 1 only: at N = 1 they coincide)
     other = None
@@ -486,7 +505,50 @@ def main():
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.width, args.height, model, fc, dev)
+        cpu = cpu_baseline(args.width, args.height, model, fc, dev, args.gop, unit)
+
+    # ---- the high-rate operating point (BASELINE configs[4] names a high-rate model: every y feature map of both
+    # networks non-zero, the serial range coder's streams at their longest), same clip, same run, outside `value`
+    high_rate = None
+    c_y = widths['c_y']
+    if rank == 0 and world == 1 and not args.no_high_rate and tuple(active_y) != (c_y, c_y):
+        model_hr = synth.make_model(widths, seed=seed, device=dev)
+        synth.calibrate_operating_point(model_hr, dev, active_y=(c_y, c_y))
+        fc_hr = FrameCodec(model_hr, max_batch=args.max_batch, entropy_streams=args.entropy_streams,
+                           entropy_lookahead=args.entropy_lookahead)
+        with torch.no_grad():
+            blobs, enc_recs, dd = fc_hr.encode_units(clips[0], args.gop)
+            dec = fc_hr.decode_units(blobs, dd, dev)
+            hr_closed = all(torch.equal(d[k], e[k]) for du, eu in zip(dec, enc_recs) for d, e in zip(du, eu) for k in 'yuv')
+            hr_errs = len(fc_hr.stream_errors())
+            del dec, enc_recs
+            torch.cuda.synchronize()
+            t0 = time.time()
+            hr_bytes, evs = 0, []
+            for i in range(args.high_rate_steps):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                blobs, _, dd = fc_hr.encode_units(clips[(args.warmup + i) % len(clips)], args.gop)
+                ev[1].record()
+                fc_hr.decode_units(blobs, dd, dev)
+                ev[2].record()
+                evs.append(ev)
+                hr_bytes += sum(len(b) for b in blobs)
+            torch.cuda.synchronize()
+            el_hr = time.time() - t0
+        enc_hr = sum(e[0].elapsed_time(e[1]) for e in evs) * 1e-3
+        dec_hr = sum(e[1].elapsed_time(e[2]) for e in evs) * 1e-3
+        high_rate = {'value': round(args.high_rate_steps * args.frames / el_hr, 4), 'unit': 'frames/s', 'steps': args.high_rate_steps,
+                     'ms_per_step': round(el_hr / args.high_rate_steps * 1e3, 2),
+                     'nonzero_y_maps': {'mofnet': c_y, 'codecnet': c_y, 'of': c_y},
+                     'bytes_per_frame': round(hr_bytes / (args.high_rate_steps * coded), 1),
+                     'encode_main_stream_fps': round(args.high_rate_steps * args.frames / enc_hr, 3),
+                     'decode_main_stream_fps': round(args.high_rate_steps * args.frames / dec_hr, 3),
+                     'closed_loop_ok': bool(hr_closed), 'stream_errors': hr_errs,
+                     'vs_headline': round(args.high_rate_steps * args.frames / el_hr / (clips_done_for_hr / elapsed), 4),
+                     'note': 'same clip and code path with the synthetic model calibrated so that every y feature map of both '
+                             'networks is coded: each frame carries two serial range-coder streams of h_y*w_y*%d symbols' % c_y}
+        del model_hr, fc_hr
 
     if rank == 0:
         # N = 1: strong and weak are the same single-process run, the label says so
@@ -521,9 +583,13 @@ def main():
             'encode_main_stream_fps_rank0': round(args.steps * args.frames / stats['enc_s'], 3),
             'decode_main_stream_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),
             'bytes_per_frame': round(stats['bytes'] / (args.steps * coded), 1),
-            'closed_loop_ok': bool(closed_loop), 'bytes_equal_single_rank': bytes_equal,
+            'closed_loop_ok': bool(closed_loop), 'stream_errors_rank0': stream_errors, 'bytes_equal_single_rank': bytes_equal,
+            # closed loop = this build's decoder on this build's bitstream: a y section written on another implementation
+            # of the transforms (the reference on ATen) desynchronises at these sizes, torchac's
+            # bytes are unpinned here (no wheel in the image)
+            'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate,
         }
         if other is not None:
             out['weak_scaling'] = other

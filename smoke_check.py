@@ -1,12 +1,13 @@
-"""smoke_check(): tiny encode + decode on cuda:0, compared with the CPU oracle.  The oracle is
-imported here only as the checker (it is test infrastructure, never part of the product path)."""
+"""smoke_check(): tiny encode + decode on cuda:0, compared with the CPU oracle.  Lives beside __graft_entry__.py,
+OUTSIDE the product package: aivc_amd/ imports nothing from oracle/ (the oracle is test infrastructure, here only as
+the checker)."""
 import numpy as np
 import torch
 
 
 def smoke_check(width=64, height=48, gop_name='1_GOP_2', n_frames=3, verbose=True):
-    from . import synth
-    from .models import arch
+    from aivc_amd import synth
+    from aivc_amd.models import arch
     from oracle import codec as ocodec
     from oracle import spec as ospec
     dev = torch.device('cuda:0')

@@ -276,6 +276,15 @@ def test_load_model_resolves_unknown_module_paths_by_class_name(tmp_path, monkey
     (tmp_path / '1_model.pt').write_bytes(raw2)
     with pytest.raises(ImportError, match='models.net.FooBNet'):
         model_management.load_model(prefix='1_', on_cpu=True)
+    # protocol-4 qualified names of nested classes resolve by walking the attributes ...
+    import collections
+    assert pickle_compat.resolve('collections', 'OrderedDict.fromkeys') == collections.OrderedDict.fromkeys
+    # ... and the by-name fallback only applies under the reference's own packages: a third-party module that happens
+    # to name a class like one of ours stays unresolved instead of binding to the local class
+    assert pickle_compat.resolve('models.anything', 'FullNet') is type(loaded)
+    assert pickle_compat.resolve('src.models.anything', 'FullNet') is type(loaded)
+    with pytest.raises(AttributeError):
+        pickle_compat.resolve('somebody_elses_pkg.nets', 'FullNet')
 
 
 def test_distributed_watchdog_names_the_wait(capfd, monkeypatch):

@@ -24,8 +24,10 @@ import os
 import sys
 import types
 
-import numpy as np
-import torch
+sys.dont_write_bytecode = True  # the reference tree is read-only input: importing it must not leave __pycache__ there
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, ROOT)
