@@ -190,11 +190,21 @@ class FrameCodec:
         (profiles/r04_band_stats_*.json: per-rank kernel time 8.0 vs 29.0 ms for a 4K B frame on 8 ranks, 5.8 vs 9.0 ms at
         1080p on 4, but 7.7 vs 9.1 ms at 1080p on 2): by default from 4 ranks per group on, or from 2 for frames of >= 6 Mpixel.
         AIVC_BAND_LEVELS=1 / 0 forces it on / off (every rank must see the same value)."""
-        if shard is None or shard.R <= 1 or n_frames >= shard.R or not getattr(shard, 'band_levels', True):
+        if shard is None or shard.R <= 1 or n_frames >= shard.R:
             return False
         force = _os.environ.get('AIVC_BAND_LEVELS')
         if force is not None:
             return force not in ('0', '')
+        # shard.band_levels: True / False set by the caller (bench.py turns it on once its warm-up clip came out
+        # byte-identical to a single-process encode over the same transport), None = automatic.  The automatic rule
+        # applies over gloo / threads, where the byte identity is tested; over RCCL the point-to-point halo exchange on
+        # a split sub-group has never run on hardware available to the build (one GPU per lease), so there it stays
+        # opt-in until a caller has verified it (tools/rccl_preflight.py --codec, bench.py).
+        mode = getattr(shard, 'band_levels', None)
+        if mode is not None:
+            return bool(mode)
+        if getattr(shard, 'backend', None) == 'nccl':
+            return False
         return shard.R >= 4 or h * w >= 6000000
 
     def encode_frame(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False):

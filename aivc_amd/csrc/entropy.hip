@@ -16,6 +16,9 @@
 //             prefetched two groups ahead because the row address never depends on coder state);
 //             "largest m with cdf[m] <= count" is a ballot + popcount instead of torchac's
 //             10-step binary search.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace aivc {
@@ -446,6 +449,166 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
   if (lane == 0) out_len[blockIdx.x] = sink.overflow ? 0xFFFFFFFFu : total;
 }
 
+// ------------------------------------------------------------------ range encoder, one stream per LANE (round 5)
+// The wave-per-stream encoder above keeps the coder state in SGPRs and pays, per symbol, two VALU -> SGPR crossings
+// (v_readlane of the two interval ends) and two to three taken branches (settled bits? straddle?): 0.09 us per symbol
+// when nothing settles, 0.16-0.18 at 2-6 bit per symbol -- and a launch of 64 streams occupies 64 wavefronts on 64 CUs
+// for as long as its longest stream, next to the convolutions.  Here a stream is a LANE: all state is per-lane VGPR
+// data, every step is straight-line VALU code (selects, no branches on the common path, so the cost does not depend
+// on the bit rate), there is no cross-lane traffic at all, and 64 streams cost ONE wavefront.  Same bytes:
+//   interval   t = (span * c) >> 16 by one v_mad_u64_u32 per end, as above
+//   E1 / E2    n = clz(low ^ high) bits are final (0 when the top bits differ): [b0][pending x ~b0][n - 1 more bits]
+//              is ONE push of n + pending <= 32 bits (longer ones take the rare loop below)
+//   E3         m = leading ones of ((low & ~high) << 1): m straddle steps, pending += m
+//   output     64-bit shifter per lane; complete 32-bit words go to a lane-private LDS ring and are written to HBM at
+//              the end of every 8-symbol chunk, BEFORE the next chunk's loads are issued: the s_waitcnt in front of a
+//              chunk's first symbol then only ever waits for stores that are a whole chunk old (vmcnt counts loads and
+//              stores in one queue)
+// Symbols past a lane's end are coded as the null symbol (bounds 0 / 2^16): t_lo = 0, t_hi = span -- the state does
+// not move and nothing is emitted.
+constexpr int ENC_CHUNK = 8, ENC_RING = 16;
+
+struct LaneSink {
+  uint32_t *dst;       // this lane's output (4-byte aligned)
+  uint32_t cap_words;
+  uint32_t widx;       // complete words produced
+  uint32_t drained;    // ... of which written to HBM
+  uint64_t acc;        // low `nbits` bits pending
+  uint32_t nbits;      // < 32 between pushes
+  uint32_t overflow;
+  uint32_t *ring;      // LDS [ENC_RING][64], this lane's column
+  // Straight-line push: the candidate word (the top 32 of the nbits accumulated bits) is written to ring slot widx on
+  // EVERY call -- garbage while the word is incomplete, overwritten until it is; widx advances when 32 bits are there.
+  __device__ __forceinline__ void push(uint32_t val, uint32_t len) {  // len in [0, 32], val < 2^len
+    acc = (acc << len) | (uint64_t)val;
+    nbits += len;
+    ring[(widx & (ENC_RING - 1)) * 64] = (uint32_t)(acc >> ((nbits - 32u) & 63u));
+    widx += nbits >> 5;
+    nbits &= 31u;
+  }
+  __device__ __forceinline__ void drain() {  // words [drained, widx) -> HBM
+    while (drained < widx) {
+      const uint32_t w = ring[(drained & (ENC_RING - 1)) * 64];
+      if (drained < cap_words) dst[drained] = __builtin_bswap32(w);
+      else overflow = 1;
+      ++drained;
+    }
+  }
+  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count) {  // (rare paths only)
+    while (count > 0) {
+      const uint32_t r = count > 32 ? 32 : count;
+      push(bit ? (r == 32 ? 0xFFFFFFFFu : ((1u << r) - 1u)) : 0u, r);
+      if (widx - drained >= ENC_RING - 2) drain();
+      count -= r;
+    }
+  }
+};
+
+// E1 / E2 output of one symbol when some lane's run of straddle bits makes it longer than one push (n + pending > 32).
+// A real call with everything by value (the state comes back in registers): inlined, the compiler merges this path's
+// pushes with the straight-line one's and the common path pays two taken branches per symbol for it.
+struct SinkRegs {
+  uint64_t acc;
+  uint32_t nbits, widx, drained, overflow;
+};
+__device__ __noinline__ SinkRegs enc_long_settle(SinkRegs r, uint32_t *dst, uint32_t cap_words, uint32_t *ring, uint32_t low,
+                                                 uint32_t n, uint32_t P) {
+  LaneSink sink{dst, cap_words, r.widx, r.drained, r.acc, r.nbits, r.overflow, ring};
+  if (n != 0) {
+    const uint32_t b0 = low >> 31;
+    sink.push(b0, 1);
+    sink.put_run(b0 ^ 1u, P);
+    sink.push((uint32_t)(((uint64_t)low << n) >> 32) & ((1u << (n - 1u)) - 1u), n - 1u);
+    if (sink.widx - sink.drained >= ENC_RING - 2) sink.drain();
+  }
+  return SinkRegs{sink.acc, sink.nbits, sink.widx, sink.drained, sink.overflow};
+}
+
+__global__ __launch_bounds__(64) void range_encode_lanes_kernel(const uint32_t *__restrict__ bounds, aivc_rc_batch batch,
+                                                                uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
+  __shared__ uint32_t ring[ENC_RING * 64];
+  const int lane = threadIdx.x;
+  const bool live = lane < batch.n_streams;
+  const aivc_rc_stream st = batch.s[live ? lane : 0];
+  const uint32_t n_sym = live ? st.n_sym : 0u;
+  uint32_t n_max = n_sym;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off));
+  n_max = __builtin_amdgcn_readfirstlane(n_max);
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t *src = bounds + st.in_off;
+  LaneSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, 0, 0, ring + lane};
+  uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+  uint32_t nxt[ENC_CHUNK];
+#pragma unroll
+  for (int k = 0; k < ENC_CHUNK; ++k) nxt[k] = (uint32_t)k < n_sym ? src[k] : 0u;
+#pragma unroll 1
+  for (uint32_t base = 0; base < n_max; base += ENC_CHUNK) {
+    uint32_t cur[ENC_CHUNK];
+#pragma unroll
+    for (int k = 0; k < ENC_CHUNK; ++k) cur[k] = nxt[k];
+#pragma unroll
+    for (int k = 0; k < ENC_CHUNK; ++k) {
+      const uint32_t i = base + ENC_CHUNK + k;
+      nxt[k] = i < n_sym ? src[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < ENC_CHUNK; ++k) {
+      const uint32_t w = cur[k];
+      const uint32_t c_lo = w & 0xFFFFu;
+      uint32_t c_hi = w >> 16;
+      c_hi = c_hi ? c_hi : 0x10000u;  // 0 = 2^16: symbol 512, and the null symbol
+      const uint32_t hl = high - low;  // span - 1
+      const uint32_t t_lo = (uint32_t)(((uint64_t)hl * c_lo + c_lo) >> 16);
+      const uint32_t t_hi = (uint32_t)(((uint64_t)hl * c_hi + c_hi) >> 16);
+      high = low + t_hi - 1u;
+      low = low + t_lo;
+      // E1 / E2: n leading bits are final
+      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);         // low < high: the operand is never 0; n <= 31
+      const uint32_t has = (uint32_t)((int32_t)(0u - n) >> 31);       // all ones when a bit settles
+      const uint32_t P = pending & has;
+      const uint32_t len = n + P;
+      if (__builtin_expect(__ballot(len > 32u) != 0ull, 0)) {          // (uniform; practically never)
+        // every lane takes the long road here (it gives the same bits for any n, P)
+        const SinkRegs r = enc_long_settle(SinkRegs{sink.acc, sink.nbits, sink.widx, sink.drained, sink.overflow}, sink.dst,
+                                           sink.cap_words, sink.ring, low, n, P);
+        sink.acc = r.acc, sink.nbits = r.nbits, sink.widx = r.widx, sink.drained = r.drained, sink.overflow = r.overflow;
+      } else {
+        // [b0][P x ~b0][the other n - 1 bits] as one value: head = b0 ? 1 << P : (1 << P) - 1, then bits 30 .. 31 - n1 of low
+        const uint32_t n1 = (n - 1u) & has;
+        const uint32_t head = ((1u << P) - 1u) + (low >> 31);
+        const uint32_t rest = ((low << 1) >> 1) >> (31u - n1);  // bits 30 .. 31 - n1 (0 for n1 = 0)
+        sink.push(((head << n1) | rest) & has, len);
+      }
+      pending &= ~has;
+      low <<= n;
+      high = (high << n) | ((1u << n) - 1u);
+      // E3: low = 0..., high = 1... now; every further position with (low, high) = (1, 0) straddles the middle
+      const uint32_t yy = (low & ~high) << 1;
+      const uint32_t m = min((uint32_t)__builtin_clz(~yy | 1u), 31u) & (0u - (yy >> 31));  // leading ones of yy (0 .. 31)
+      pending += m;
+      low = (low << m) & 0x7FFFFFFFu;
+      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+    }
+    sink.drain();
+  }
+  if (live) {
+    pending += 1;
+    const uint32_t fb = low < 0x40000000u ? 0u : 1u;
+    sink.push(fb, 1);
+    sink.put_run(fb ^ 1u, pending);
+    sink.drain();
+    if (sink.nbits > 0) {  // bits left over after the last complete word: MSB aligned, zero padded
+      const uint32_t w = (uint32_t)(sink.acc << (32 - sink.nbits));
+      if (sink.widx < sink.cap_words) sink.dst[sink.widx] = __builtin_bswap32(w);
+      else sink.overflow = 1;
+    }
+    const uint32_t total = sink.widx * 4u + (sink.nbits + 7u) / 8u;
+    if (total > st.out_cap) sink.overflow = 1;
+    out_len[lane] = sink.overflow ? 0xFFFFFFFFu : total;
+  }
+}
+
 // ------------------------------------------------------------------ range decoder
 // Per symbol torchac computes count = ((value - low + 1) * 2^16 - 1) / span, binary-searches the largest m with
 // cdf[m] <= count, then narrows  high = low - 1 + (span * cdf[m + 1] >> 16),  low = low + (span * cdf[m] >> 16).
@@ -834,8 +997,12 @@ AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *b
     if (batch->s[i].out_off % 4) return AIVC_ERR_ARG;
     if (batch->s[i].n_sym && !bounds) return AIVC_ERR_ARG;
   }
-  hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch,
-                     out, out_len);
+  // one stream per lane (one wavefront for the whole batch) unless AIVC_RC_ENCODE=wave asks for the wave-per-stream kernel
+  const char *mode = getenv("AIVC_RC_ENCODE");  // (read per call: the tests run both kernels in one process)
+  if (mode && !strcmp(mode, "wave"))
+    hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch, out, out_len);
+  else
+    hipLaunchKernelGGL(range_encode_lanes_kernel, dim3(1), dim3(64), 0, to_stream(stream), bounds, *batch, out, out_len);
   return check_launch("range_encode");
 }
 

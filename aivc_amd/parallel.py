@@ -301,6 +301,8 @@ class ClipShard:
         self.n_units = n_units
         self.device = device
         self.pg = None
+        self.backend = dist.get_backend() if is_dist() else None
+        self.band_levels = None  # row bands for levels narrower than the group: None = FrameCodec._banded's rule
         if self.world > 1:
             for g in range(self.G):
                 ranks = list(range(g * self.R, (g + 1) * self.R))

@@ -374,15 +374,36 @@ def main():
         return el
 
     # ---- warm-up; closed loop (decoder == encoder reconstruction) and, for the sharded path, bytes == single rank
-    closed_loop, bytes_equal = True, None
-    for i in range(args.warmup):
-        blobs, dd, enc_recs, dec = step(clips[i], sh=shard)
-        if enc_recs is None:  # sharded: this rank's own single-process encode of the same clip is the reference
-            with torch.no_grad():
-                ref_blobs, enc_recs, _ = fc.encode_units(clips[i], args.gop)
-            bytes_equal = (bytes_equal is not False) and blobs == ref_blobs
-        for u, frs in dec.items():
-            closed_loop &= all(torch.equal(d[k], e[k]) for d, e in zip(frs, enc_recs[u]) for k in 'yuv')
+    def warm_up():
+        closed, equal = True, None
+        for i in range(args.warmup):
+            blobs, dd, enc_recs, dec = step(clips[i], sh=shard)
+            if enc_recs is None:  # sharded: this rank's own single-process encode of the same clip is the reference
+                with torch.no_grad():
+                    ref_blobs, enc_recs, _ = fc.encode_units(clips[i], args.gop)
+                equal = (equal is not False) and blobs == ref_blobs
+            for u, frs in dec.items():
+                closed &= all(torch.equal(d[k], e[k]) for d, e in zip(frs, enc_recs[u]) for k in 'yuv')
+        if use_dist:  # the verdict of every rank
+            t = torch.tensor([0 if (closed and equal is not False) else 1], device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t)
+            if int(t.item()):
+                equal = False if equal is not None else equal
+                closed = closed and equal is not None
+        return closed, equal
+
+    # Levels with fewer frames than a group has ranks can be coded in row bands over the group (aivc_amd/bands.py); over
+    # RCCL that transport (point-to-point halo exchange on a split sub-group) is taken only after THIS run has verified
+    # it: the warm-up clip must come out byte-identical to the single-process encode, otherwise bands are switched off
+    # on every rank and the warm-up is repeated.  (A first-contact hang is named by tools/rccl_preflight.py --codec.)
+    row_bands = None
+    if shard is not None and shard.R > 1 and os.environ.get('AIVC_BAND_LEVELS') is None and args.warmup > 0 \
+            and (shard.R >= 4 or args.width * args.height >= 6000000):
+        shard.band_levels, row_bands = True, 'on (warm-up clip byte-identical to the single-process encode)'
+    closed_loop, bytes_equal = warm_up()
+    if row_bands and not (closed_loop and bytes_equal is not False):
+        shard.band_levels, row_bands = False, 'switched off: the warm-up clip coded in row bands differed from the single-process encode'
+        closed_loop, bytes_equal = warm_up()
     if bytes_equal is False:
         raise SystemExit('bench.py: sharded bitstream differs from the single-rank bitstream')
     elapsed = timed_run(shard, args.warmup)
@@ -584,6 +605,7 @@ def main():
             'decode_main_stream_fps_rank0': round(args.steps * args.frames / stats['dec_s'], 3),
             'bytes_per_frame': round(stats['bytes'] / (args.steps * coded), 1),
             'closed_loop_ok': bool(closed_loop), 'stream_errors_rank0': stream_errors, 'bytes_equal_single_rank': bytes_equal,
+            'row_bands': row_bands,
             # closed loop = this build's decoder on this build's bitstream: a y section written on another implementation
             # of the transforms (the reference on ATen) desynchronises at these sizes, torchac's
             # bytes are unpinned here (no wheel in the image)

@@ -62,6 +62,8 @@ CONV_CASES = [
     (abi.MODE_TCONV, 5, 2, 0, 48, 6, 8, 33, 0, abi.ACT_LEAKY, True, True),
     (abi.MODE_TCONV, 3, 2, 0, 96, 3, 1, 1, 0, 0, False, False),
     (abi.MODE_TCONV, 5, 2, 0, 64, 6, 6, 10, abi.ACT_SIGMOID, 0, False, False),  # falls back to the VALU kernel
+    (abi.MODE_TCONV, 5, 2, 0, 64, 3, 7, 70, abi.ACT_RELU, 0, False, False),     # lean epilogue, relu (+0.0 for negatives)
+    (abi.MODE_TCONV, 5, 2, 0, 32, 6, 5, 33, abi.ACT_LEAKY, 0, False, False),
     # LDS-DMA K loop corner cases: a reduction of ONE K-tile (1x1, c_in 32), of an odd number (3x3 x 32 = 9), two
     # tiles; transposed with image-border zero fill on every tile; c_out beyond the tile width; rows beyond M
     (abi.MODE_CONV, 1, 1, 0, 32, 64, 9, 13, 0, 0, False, False),
@@ -93,6 +95,25 @@ def test_conv_family_bit_exact(case, algo, oracle, cuda):
                      mul=None if mul is None else T(mul, cuda), res=None if res is None else T(res, cuda),
                      algo=algo)
     eq(got, ref)
+
+
+@pytest.mark.parametrize('grid', [1, 3, 7])
+@pytest.mark.parametrize('co,k,ci,h,w', [(3, 5, 64, 21, 100), (6, 5, 64, 9, 70), (3, 3, 16, 13, 65)])
+def test_thin_layer_tile_walk(grid, co, k, ci, h, w, oracle, cuda, monkeypatch):
+    """The thin output layer's persistent groups walk several tiles each (origins advanced without divisions across tile
+    rows and images, double-buffered patches, epilogue of the previous tile inside the next chain): forced here at
+    small sizes with AIVC_THIN_GRID_MAX groups over 3 images, bit exact against the oracle -- with and without bias."""
+    from aivc_amd import ops
+    monkeypatch.setenv('AIVC_THIN_GRID_MAX', str(grid))
+    rng = np.random.default_rng(grid * 100 + co)
+    x = rng.standard_normal((3, h, w, ci), dtype=np.float32)
+    wt = (rng.standard_normal((co, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)
+    bias = rng.standard_normal(co, dtype=np.float32)
+    for b in (bias, None):
+        ref = oracle.conv2d(x, wt, b, mode=abi.MODE_TCONV, stride=2, pad=0, act1=abi.ACT_LEAKY)
+        got = ops.conv2d(T(x, cuda), T(wt, cuda), None if b is None else T(b, cuda), mode=abi.MODE_TCONV, stride=2, pad=0,
+                         act1=abi.ACT_LEAKY)
+        eq(got, ref)
 
 
 def test_frame_ops_bit_exact(oracle, cuda):
@@ -240,6 +261,50 @@ def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
     # bits shifted in by renormalisation: same count as the oracle's, and it accounts for the payload length
     _, ref_bits = oracle.range_decode(ref_bytes, rows, n_sym, want_bits=True)
     assert int(bits.cpu()[0]) == ref_bits and len(ref_bytes) == (ref_bits + 2 + 7) // 8
+
+
+def _straddle_stream(rng, n, burst):
+    """packed (c_lo | c_hi << 16) bounds whose intervals keep sitting across the middle of the coder's range: every such
+    symbol adds ~14 straddle (E3) steps to the pending count, `burst` of them in a row push it past 32 and far beyond,
+    then a symbol that settles releases the run -- the encoder's long-run path, followed by ordinary symbols"""
+    out = []
+    while len(out) < n:
+        for _ in range(int(rng.integers(1, burst + 1))):
+            d = int(rng.integers(1, 4))
+            out.append((0x8000 - d) | ((0x8000 + int(rng.integers(1, 4))) << 16))
+        lo = int(rng.integers(0, 0xF000))
+        out.append(lo | ((lo + int(rng.integers(1, 0x0FFF))) << 16))
+        for _ in range(int(rng.integers(0, 40))):
+            lo = int(rng.integers(0, 0xFFF0))
+            hi = lo + int(rng.integers(1, 0x10000 - lo))
+            out.append(lo | ((hi & 0xFFFF) << 16))  # hi = 2^16 packs as 0
+    return np.array(out[:n], np.uint32)
+
+
+@pytest.mark.parametrize('kernel', ['lanes', 'wave'])
+def test_range_encoder_batches_ragged_streams_and_long_straddle_runs(kernel, oracle, cuda, monkeypatch):
+    """A batch of streams in ONE launch (the stream-per-lane encoder codes them side by side in one wavefront, the
+    wave-per-stream encoder one wavefront each): ragged lengths incl. empty, 1, 7, 8, 9 symbols (chunk edges), more than
+    64 streams (two launches), ordinary Laplace symbols and adversarial straddle runs (pending count up to hundreds: the
+    output of one symbol is longer than a word) -- every stream's bytes == the oracle's."""
+    from aivc_amd import ops
+    monkeypatch.setenv('AIVC_RC_ENCODE', kernel)
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 500, 2049] + [int(v) for v in rng.integers(1, 3000, 60)]
+    streams = []
+    for i, n in enumerate(lens):
+        if i % 3 == 2:
+            streams.append(_straddle_stream(rng, n, burst=1 + i % 9))
+        else:
+            sig = np.clip(np.exp(rng.uniform(np.log(0.05), np.log(40.0), (1, 1, max(n, 1), 1))), 1e-4, 148.4).astype(np.float32)
+            q = np.clip(np.rint(rng.laplace(0, 1, sig.shape) * sig / np.sqrt(2)), -256, 255).astype(np.int16)
+            streams.append(oracle.laplace_bounds(sig, q, [0])[:n])
+    want = [oracle.range_encode(b) for b in streams]
+    assert max(len(w) for w in want) > 0
+    out, ln, offs = ops.range_encode([T(np.ascontiguousarray(b).view(np.int32), cuda) for b in streams])
+    out_h, ln_h = out.cpu().numpy(), ln.cpu().numpy()
+    for i, ((off, cap), n, w) in enumerate(zip(offs, ln_h, want)):
+        assert out_h[off:off + int(n)].tobytes() == w, (kernel, i, lens[i])
 
 
 @pytest.mark.parametrize('scale', [0.4, 3.0, 40.0])
