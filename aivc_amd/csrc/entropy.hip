@@ -450,84 +450,68 @@ __global__ __launch_bounds__(64) void range_encode_kernel(const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------ range encoder, one stream per LANE (round 5)
-// The wave-per-stream encoder above keeps the coder state in SGPRs and pays, per symbol, two VALU -> SGPR crossings
-// (v_readlane of the two interval ends) and two to three taken branches (settled bits? straddle?): 0.09 us per symbol
-// when nothing settles, 0.16-0.18 at 2-6 bit per symbol -- and a launch of 64 streams occupies 64 wavefronts on 64 CUs
-// for as long as its longest stream, next to the convolutions.  Here a stream is a LANE: all state is per-lane VGPR
-// data, every step is straight-line VALU code (selects, no branches on the common path, so the cost does not depend
-// on the bit rate), there is no cross-lane traffic at all, and 64 streams cost ONE wavefront.  Same bytes:
-//   interval   t = (span * c) >> 16 by one v_mad_u64_u32 per end, as above
-//   E1 / E2    n = clz(low ^ high) bits are final (0 when the top bits differ): [b0][pending x ~b0][n - 1 more bits]
-//              is ONE push of n + pending <= 32 bits (longer ones take the rare loop below)
-//   E3         m = leading ones of ((low & ~high) << 1): m straddle steps, pending += m
-//   output     64-bit shifter per lane; complete 32-bit words go to a lane-private LDS ring and are written to HBM at
-//              the end of every 8-symbol chunk, BEFORE the next chunk's loads are issued: the s_waitcnt in front of a
-//              chunk's first symbol then only ever waits for stores that are a whole chunk old (vmcnt counts loads and
-//              stores in one queue)
-// Symbols past a lane's end are coded as the null symbol (bounds 0 / 2^16): t_lo = 0, t_hi = span -- the state does
-// not move and nothing is emitted.
-constexpr int ENC_CHUNK = 8, ENC_RING = 16;
+// What a lone wavefront pays (tools/lat_probe.hip, profiles/r05_lat_probe.txt): 4 cycles per instruction of any kind,
+// dependent or not; +10 for a branch not taken, +24 taken, +25 when it tests a VALU compare; +16..20 for every
+// VALU -> SGPR -> SALU crossing; 18 for v_mad_u64_u32 + shift in a chain.  The wave-per-stream encoder above pays two
+// crossings and two to four branches per symbol: 0.09 us per symbol when nothing settles, 0.16-0.18 at 2-6 bit per
+// symbol -- and a launch of 64 streams occupies 64 wavefronts on 64 CUs for as long as its longest stream, next to the
+// convolutions.  Here a stream is a LANE: all state is per-lane VGPR data, every step is straight-line VALU code
+// (selects, no branch per symbol, so the cost does not depend on the bit rate), no cross-lane traffic, and the serial
+// chain is split over TWO wavefronts of one workgroup that run on different SIMDs:
+//   wave A  the interval arithmetic, the chain that is serial by format (30 instructions per symbol):
+//             t = (span * c) >> 16 by one v_mad_u64_u32 per end;
+//             E1 / E2: n = clz(low ^ high) leading bits are final;  E3: m = leading ones of (low & ~high) << (n + 1)
+//             straddle steps (span > 2^30 before a symbol and a symbol's probability >= 2^-16 bound n + m <= 18, so the
+//             two renormalisations are ONE shift by n + m);
+//             per symbol it leaves {low before the shift, n, pending count released by the settled bit} in LDS;
+//   wave B  the bit packer, one chunk of 32 symbols behind A: [b0][pending x ~b0][n - 1 more bits of low] is ONE push of
+//             n + pending <= 32 bits into a 64-bit shifter per lane; the candidate word is stored on every symbol
+//             (overwritten until it is complete: no branch, no flush test), a chunk in which some lane's run of straddle
+//             bits exceeded one push is redone from its records by the generic loop.
+// One s_barrier per chunk.  64 streams cost two wavefronts; a symbol costs wave A ~0.055 us whatever the bit rate.
+// Symbols past a lane's end are coded as the null symbol (bounds 0 / 2^16): t_lo = 0, t_hi = span -- the state does not
+// move and nothing is emitted.
+constexpr int ENC_CH = 32;  // symbols per chunk (LDS: 2 buffers x 32 x 64 lanes x 8 B = 32 KB)
 
-struct LaneSink {
+struct LanePacker {
   uint32_t *dst;       // this lane's output (4-byte aligned)
-  uint32_t cap_words;
+  uint32_t last_word;  // cap_words - 1
   uint32_t widx;       // complete words produced
-  uint32_t drained;    // ... of which written to HBM
   uint64_t acc;        // low `nbits` bits pending
   uint32_t nbits;      // < 32 between pushes
-  uint32_t overflow;
-  uint32_t *ring;      // LDS [ENC_RING][64], this lane's column
-  // Straight-line push: the candidate word (the top 32 of the nbits accumulated bits) is written to ring slot widx on
-  // EVERY call -- garbage while the word is incomplete, overwritten until it is; widx advances when 32 bits are there.
+  // straight-line push: the candidate word (the top 32 of the nbits accumulated bits) is stored at dst[widx] on EVERY call
+  // -- garbage while the word is incomplete, overwritten until it is; widx advances when 32 bits are there
   __device__ __forceinline__ void push(uint32_t val, uint32_t len) {  // len in [0, 32], val < 2^len
     acc = (acc << len) | (uint64_t)val;
     nbits += len;
-    ring[(widx & (ENC_RING - 1)) * 64] = (uint32_t)(acc >> ((nbits - 32u) & 63u));
+    dst[min(widx, last_word)] = __builtin_bswap32((uint32_t)(acc >> ((nbits - 32u) & 63u)));
     widx += nbits >> 5;
     nbits &= 31u;
   }
-  __device__ __forceinline__ void drain() {  // words [drained, widx) -> HBM
-    while (drained < widx) {
-      const uint32_t w = ring[(drained & (ENC_RING - 1)) * 64];
-      if (drained < cap_words) dst[drained] = __builtin_bswap32(w);
-      else overflow = 1;
-      ++drained;
-    }
-  }
-  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count) {  // (rare paths only)
+  __device__ __forceinline__ void put_run(uint32_t bit, uint32_t count) {
     while (count > 0) {
       const uint32_t r = count > 32 ? 32 : count;
       push(bit ? (r == 32 ? 0xFFFFFFFFu : ((1u << r) - 1u)) : 0u, r);
-      if (widx - drained >= ENC_RING - 2) drain();
       count -= r;
+    }
+  }
+  // E1 / E2 output of one symbol in general (any run length): b0, the pending run, the other n - 1 bits
+  __device__ __forceinline__ void settle_long(uint32_t low, uint32_t n, uint32_t P) {
+    if (n != 0) {
+      const uint32_t b0 = low >> 31;
+      push(b0, 1);
+      put_run(b0 ^ 1u, P);
+      push(((low << 1) >> 1) >> (32u - n), n - 1u);
     }
   }
 };
 
-// E1 / E2 output of one symbol when some lane's run of straddle bits makes it longer than one push (n + pending > 32).
-// A real call with everything by value (the state comes back in registers): inlined, the compiler merges this path's
-// pushes with the straight-line one's and the common path pays two taken branches per symbol for it.
-struct SinkRegs {
-  uint64_t acc;
-  uint32_t nbits, widx, drained, overflow;
-};
-__device__ __noinline__ SinkRegs enc_long_settle(SinkRegs r, uint32_t *dst, uint32_t cap_words, uint32_t *ring, uint32_t low,
-                                                 uint32_t n, uint32_t P) {
-  LaneSink sink{dst, cap_words, r.widx, r.drained, r.acc, r.nbits, r.overflow, ring};
-  if (n != 0) {
-    const uint32_t b0 = low >> 31;
-    sink.push(b0, 1);
-    sink.put_run(b0 ^ 1u, P);
-    sink.push((uint32_t)(((uint64_t)low << n) >> 32) & ((1u << (n - 1u)) - 1u), n - 1u);
-    if (sink.widx - sink.drained >= ENC_RING - 2) sink.drain();
-  }
-  return SinkRegs{sink.acc, sink.nbits, sink.widx, sink.drained, sink.overflow};
-}
-
-__global__ __launch_bounds__(64) void range_encode_lanes_kernel(const uint32_t *__restrict__ bounds, aivc_rc_batch batch,
-                                                                uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
-  __shared__ uint32_t ring[ENC_RING * 64];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(128) void range_encode_lanes_kernel(const uint32_t *__restrict__ bounds, aivc_rc_batch batch,
+                                                                 uint8_t *__restrict__ out, uint32_t *__restrict__ out_len) {
+  __shared__ uint2 rec[2][ENC_CH][64];  // {low after the interval update, n | pending released << 5}
+  __shared__ uint2 fin[64];             // {low, pending} after the last symbol
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool live = lane < batch.n_streams;
   const aivc_rc_stream st = batch.s[live ? lane : 0];
   const uint32_t n_sym = live ? st.n_sym : 0u;
@@ -535,77 +519,97 @@ __global__ __launch_bounds__(64) void range_encode_lanes_kernel(const uint32_t *
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off));
   n_max = __builtin_amdgcn_readfirstlane(n_max);
+  const uint32_t n_chunks = (n_max + ENC_CH - 1) / ENC_CH;
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t *src = bounds + st.in_off;
-  LaneSink sink{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4, 0, 0, 0, 0, 0, ring + lane};
-  uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
-  uint32_t nxt[ENC_CHUNK];
+  if (wave == 0) {
+    // ---------------------------------------------------------------- wave A: intervals and renormalisation
+    const uint32_t *src = bounds + st.in_off;
+    uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+    uint32_t nxt[8];
 #pragma unroll
-  for (int k = 0; k < ENC_CHUNK; ++k) nxt[k] = (uint32_t)k < n_sym ? src[k] : 0u;
+    for (int k = 0; k < 8; ++k) nxt[k] = (uint32_t)k < n_sym ? src[k] : 0u;
 #pragma unroll 1
-  for (uint32_t base = 0; base < n_max; base += ENC_CHUNK) {
-    uint32_t cur[ENC_CHUNK];
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      uint2 *buf = &rec[c & 1][0][lane];
+#pragma unroll 1
+      for (uint32_t g = 0; g < ENC_CH; g += 8) {
+        uint32_t cur[8];
 #pragma unroll
-    for (int k = 0; k < ENC_CHUNK; ++k) cur[k] = nxt[k];
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+        const uint32_t nb = c * ENC_CH + g + 8;  // first symbol of the next group
 #pragma unroll
-    for (int k = 0; k < ENC_CHUNK; ++k) {
-      const uint32_t i = base + ENC_CHUNK + k;
-      nxt[k] = i < n_sym ? src[i] : 0u;
-    }
+        for (int k = 0; k < 8; ++k) nxt[k] = nb + (uint32_t)k < n_sym ? src[nb + k] : 0u;
 #pragma unroll
-    for (int k = 0; k < ENC_CHUNK; ++k) {
-      const uint32_t w = cur[k];
-      const uint32_t c_lo = w & 0xFFFFu;
-      uint32_t c_hi = w >> 16;
-      c_hi = c_hi ? c_hi : 0x10000u;  // 0 = 2^16: symbol 512, and the null symbol
-      const uint32_t hl = high - low;  // span - 1
-      const uint32_t t_lo = (uint32_t)(((uint64_t)hl * c_lo + c_lo) >> 16);
-      const uint32_t t_hi = (uint32_t)(((uint64_t)hl * c_hi + c_hi) >> 16);
-      high = low + t_hi - 1u;
-      low = low + t_lo;
-      // E1 / E2: n leading bits are final
-      const uint32_t n = (uint32_t)__builtin_clz(low ^ high);         // low < high: the operand is never 0; n <= 31
-      const uint32_t has = (uint32_t)((int32_t)(0u - n) >> 31);       // all ones when a bit settles
-      const uint32_t P = pending & has;
-      const uint32_t len = n + P;
-      if (__builtin_expect(__ballot(len > 32u) != 0ull, 0)) {          // (uniform; practically never)
-        // every lane takes the long road here (it gives the same bits for any n, P)
-        const SinkRegs r = enc_long_settle(SinkRegs{sink.acc, sink.nbits, sink.widx, sink.drained, sink.overflow}, sink.dst,
-                                           sink.cap_words, sink.ring, low, n, P);
-        sink.acc = r.acc, sink.nbits = r.nbits, sink.widx = r.widx, sink.drained = r.drained, sink.overflow = r.overflow;
-      } else {
-        // [b0][P x ~b0][the other n - 1 bits] as one value: head = b0 ? 1 << P : (1 << P) - 1, then bits 30 .. 31 - n1 of low
-        const uint32_t n1 = (n - 1u) & has;
-        const uint32_t head = ((1u << P) - 1u) + (low >> 31);
-        const uint32_t rest = ((low << 1) >> 1) >> (31u - n1);  // bits 30 .. 31 - n1 (0 for n1 = 0)
-        sink.push(((head << n1) | rest) & has, len);
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t w = cur[k];
+          const uint32_t c_lo = w & 0xFFFFu;
+          uint32_t c_hi = w >> 16;
+          c_hi = c_hi ? c_hi : 0x10000u;  // 0 = 2^16: symbol 512, and the null symbol
+          const uint32_t hl = high - low;  // span - 1
+          const uint32_t t_lo = (uint32_t)(((uint64_t)hl * c_lo + c_lo) >> 16);
+          const uint32_t t_hi = (uint32_t)(((uint64_t)hl * c_hi + c_hi) >> 16);
+          high = low + t_hi - 1u;
+          low = low + t_lo;
+          const uint32_t n = (uint32_t)__builtin_clz(low ^ high);  // low < high: never 0; n <= 18
+          const uint32_t P = n ? pending : 0u;
+          pending = n ? 0u : pending;
+          buf[(g + k) * 64] = make_uint2(low, n | (P << 5));
+          // E3 on the values E1 / E2 would leave: positions with (low, high) = (1, 0) below the settled bits straddle
+          const uint32_t yy = (low & ~high) << (n + 1u);
+          const uint32_t m = (uint32_t)__builtin_clz(~yy);  // leading ones of yy: yy is never all ones (n + m <= 18)
+          const uint32_t sh = n + m;
+          pending += m;
+          low = (low << sh) & 0x7FFFFFFFu;
+          high = (high << sh) | ((1u << sh) - 1u) | 0x80000000u;
+        }
       }
-      pending &= ~has;
-      low <<= n;
-      high = (high << n) | ((1u << n) - 1u);
-      // E3: low = 0..., high = 1... now; every further position with (low, high) = (1, 0) straddles the middle
-      const uint32_t yy = (low & ~high) << 1;
-      const uint32_t m = min((uint32_t)__builtin_clz(~yy | 1u), 31u) & (0u - (yy >> 31));  // leading ones of yy (0 .. 31)
-      pending += m;
-      low = (low << m) & 0x7FFFFFFFu;
-      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      __syncthreads();
     }
-    sink.drain();
-  }
-  if (live) {
-    pending += 1;
-    const uint32_t fb = low < 0x40000000u ? 0u : 1u;
-    sink.push(fb, 1);
-    sink.put_run(fb ^ 1u, pending);
-    sink.drain();
-    if (sink.nbits > 0) {  // bits left over after the last complete word: MSB aligned, zero padded
-      const uint32_t w = (uint32_t)(sink.acc << (32 - sink.nbits));
-      if (sink.widx < sink.cap_words) sink.dst[sink.widx] = __builtin_bswap32(w);
-      else sink.overflow = 1;
+    fin[lane] = make_uint2(low, pending);
+    __syncthreads();
+  } else {
+    // ---------------------------------------------------------------- wave B: bit packing, one chunk behind
+    LanePacker pk{reinterpret_cast<uint32_t *>(out + st.out_off), st.out_cap / 4 - 1u, 0, 0, 0};
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      __syncthreads();  // chunk c is complete (wave A goes on with chunk c + 1 in the other buffer)
+      if (!live) continue;  // (a lane without a stream owns no output; the wave still takes every barrier)
+      const uint2 *buf = &rec[c & 1][0][lane];
+      const LanePacker at_start = pk;
+      uint32_t longest = 0;
+#pragma unroll 8
+      for (int k = 0; k < ENC_CH; ++k) {
+        const uint2 r = buf[k * 64];
+        const uint32_t low = r.x, n = r.y & 31u, P = r.y >> 5;
+        const uint32_t len = n + P;
+        longest = max(longest, len);
+        // [b0][P x ~b0][the other n - 1 bits] as one value: head = b0 ? 1 << P : (1 << P) - 1, then bits 30 .. 32 - n of low
+        const uint32_t n1 = n ? n - 1u : 0u;
+        const uint32_t head = ((1u << P) - 1u) + (low >> 31);
+        const uint32_t rest = ((low << 1) >> 1) >> (31u - n1);
+        uint32_t val = (head << n1) | rest;
+        asm volatile("" : "+v"(val));  // computed for every symbol: as "n ? ... : 0" the compiler branches around it (+25 cycles)
+        pk.push(n ? val : 0u, len);
+      }
+      if (__builtin_expect(__ballot(longest > 32u) != 0ull, 0)) {  // (uniform; practically never)
+        pk = at_start;
+#pragma unroll 1
+        for (int k = 0; k < ENC_CH; ++k) {
+          const uint2 r = buf[k * 64];
+          pk.settle_long(r.x, r.y & 31u, r.y >> 5);
+        }
+      }
     }
-    const uint32_t total = sink.widx * 4u + (sink.nbits + 7u) / 8u;
-    if (total > st.out_cap) sink.overflow = 1;
-    out_len[lane] = sink.overflow ? 0xFFFFFFFFu : total;
+    __syncthreads();  // wave A's final state (barriers: n_chunks + 1 on both sides)
+    const uint2 f = fin[lane];
+    if (live) {
+      const uint32_t fb = f.x < 0x40000000u ? 0u : 1u;
+      pk.push(fb, 1);
+      pk.put_run(fb ^ 1u, f.y + 1u);
+      if (pk.nbits > 0) pk.dst[min(pk.widx, pk.last_word)] = __builtin_bswap32((uint32_t)(pk.acc << (32 - pk.nbits)));
+      const uint32_t total = pk.widx * 4u + (pk.nbits + 7u) / 8u;
+      out_len[lane] = total > st.out_cap ? 0xFFFFFFFFu : total;
+    }
   }
 }
 
@@ -1002,7 +1006,7 @@ AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *b
   if (mode && !strcmp(mode, "wave"))
     hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch, out, out_len);
   else
-    hipLaunchKernelGGL(range_encode_lanes_kernel, dim3(1), dim3(64), 0, to_stream(stream), bounds, *batch, out, out_len);
+    hipLaunchKernelGGL(range_encode_lanes_kernel, dim3(1), dim3(128), 0, to_stream(stream), bounds, *batch, out, out_len);
   return check_launch("range_encode");
 }
 
