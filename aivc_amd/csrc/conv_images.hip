@@ -178,9 +178,6 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     int b, oy0, ox0;
     tile_of(t, b, oy0, ox0);
     __syncthreads();  // lut / weights (first tile); everybody is done with the previous tile's squares
-#ifdef IC_EXP_NO_STAGE
-    if (a.n < 0)
-#endif
     {
       int tt = tid;
       asm volatile("" : "+v"(tt));
@@ -200,9 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       }
     }
     __syncthreads();
-#ifndef IC_EXP_NO_STAGE
     if (t + 1 < t_end) fetch(t + 1);  // in flight during this tile's matrix work
-#endif
 
     // ---- main loop: operands straight from LDS --------------------------------------------------
     floatx16 acc[2];
@@ -210,9 +205,6 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-#ifdef IC_EXP_NO_MFMA  // tuning aid (tools/build_images_exp.sh): phase decomposition
-    if (a.n < 0)
-#endif
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       // compile-time offsets of quads 2 o (lanes 0-31) and 2 o + 1 (lanes 32-63)
@@ -288,11 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes; the normalisation / activation
     // variant and the edge masking are chosen once per tile (uniform branch), not per element
     const int oy = oy0 + wave;
-#ifdef IC_EXP_NO_EPI
-    if (a.n < 0 && oy < a.ho) {
-#else
     if (oy < a.ho) {
-#endif
       // wave-uniform row base (scalar registers) + one 32-bit lane offset: the 32 store addresses of a lane are
       // immediates off it (as 64-bit per-element pointers they were what the kernel spilled)
       const uint64_t yb64 = (uint64_t)(uintptr_t)(a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO);

@@ -41,16 +41,13 @@ struct MfmaArgs {
   uint32_t w_magic, h_magic;  // floor(2^32 / w_in), floor(2^32 / h_in): quotient low by at most one
   int gx, gy;                  // pixel tiles, c_out tiles (the grid is 1-D: gx x gy x parity classes)
   int tc_order;                // transposed conv: 1 = XCD-contiguous tile runs inside a parity class
-#ifdef AIVC_EXP_STAGGER
-  int stagger, first_round;
-#endif
 };
 
 constexpr int BK = 32;
 constexpr int OCT = BK / 8;  // 8-float units per LDS row
 constexpr int LDS_STRIDE = BK + 4;
 
-#ifdef AIVC_PHASE_TIMING
+#ifdef AIVC_TUNING  // per-workgroup phase timestamps (tools/phase_probe.py builds a copy with -DAIVC_TUNING; never in the product library)
 __device__ unsigned long long aivc_dbg_t[8 * 8192];
 #define DBG_T(i) if (threadIdx.x == 0 && blockIdx.x < 8192) aivc_dbg_t[blockIdx.x * 8 + (i)] = (i) == 0 || (i) == 5 ? wall_clock64() : clock64()
 #else
@@ -80,17 +77,11 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   DBG_T(0);
   DBG_T(1);
-#ifdef AIVC_PHASE_TIMING
+#ifdef AIVC_TUNING  // per-workgroup phase timestamps (tools/phase_probe.py builds a copy with -DAIVC_TUNING; never in the product library)
   if (threadIdx.x == 0 && blockIdx.x < 8192) aivc_dbg_t[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
 #endif
   float *As = smem;
   float *Bs = smem + BM * LDS_STRIDE;
-#ifdef AIVC_EXP_STAGGER
-  if (a.stagger > 0 && blockIdx.x < (uint32_t)a.first_round) {
-    const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_ID.WAVE_ID
-    for (uint32_t i = 0; i < slot * (uint32_t)a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
 
   const aivc_conv_params &p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1101,7 +1092,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
   DBG_T(5);
 }
 
-#ifdef AIVC_PHASE_TIMING
+#ifdef AIVC_TUNING  // per-workgroup phase timestamps (tools/phase_probe.py builds a copy with -DAIVC_TUNING; never in the product library)
 extern "C" __attribute__((visibility("default"))) int aivc_dbg_dump(unsigned long long *host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(aivc_dbg_t), sizeof(unsigned long long) * (size_t)n);
 }
@@ -1121,13 +1112,6 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   static const int tc_order = getenv("AIVC_TCONV_ORDER") ? atoi(getenv("AIVC_TCONV_ORDER")) : 1;  // tuning aid: 0 = plain dispatch order
   a.tc_order = tc_order;
   dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
-#ifdef AIVC_EXP_STAGGER
-  {
-    const char *e = getenv("AIVC_STAGGER"), *f = getenv("AIVC_FIRST_ROUND");
-    a.stagger = e ? atoi(e) : 0;
-    a.first_round = f ? atoi(f) : 512;
-  }
-#endif
   size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
   if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   if (lds > 64 * 1024) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tuning aid: per-workgroup phase times of conv_mfma (needs the -DAIVC_PHASE_TIMING build of tools/build_exp.sh).
+"""Tuning aid: per-workgroup phase times of conv_mfma (needs the -DAIVC_TUNING build of tools/build_exp.sh).
 usage: AIVC_HIP_LIB=aivc_amd/lib/exp/timing.so [BATCH=8 FUSE_GDN=1] phase_probe.py <shape-index>"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
