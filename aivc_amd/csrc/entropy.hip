@@ -692,27 +692,26 @@ struct BitWin {
   }
 };
 
-constexpr int DEC_D = 16;      // window prefetch depth (symbols): LDS ring of DEC_D slots
+constexpr int DEC_HALF = 32;   // symbols per half of the window ring: the prefetching wave fills one half while the decoding wave reads the other
+constexpr int DEC_SLOTS = 2 * DEC_HALF + 1;  // (+ 1: the decoding wave reads one slot ahead, past the end of the second half at a block's last symbol)
 constexpr int DEC_WIN0 = 224;  // fast-path window: CDF entries 224..287 (symbol values -32..+31), one per lane
 static_assert(DEC_WIN0 == CDF_WIN0, "window position");
 
 // LDS-DMA of one uint16 per lane (128 contiguous bytes of the row -> one dword per lane in LDS, zero-extended): no
-// register, invisible to the compiler's s_waitcnt bookkeeping (an ordinary prefetch makes hipcc wait vmcnt(0) at
-// the next use of ANY load result in this branchy loop, i.e. for the load it has just issued: measured 0.33 us per
-// symbol, most of it that wait).  Completion is counted by hand: one DMA per symbol, in order,
-// `s_waitcnt vmcnt(DEC_D - 1)` before the slot is read.  Address = uniform row base + per-lane 32-bit byte offset;
-// M0 (the LDS destination base) is written in the statement that uses it (nothing else in these kernels touches M0:
-// gfx9 LDS instructions do not need it).
+// register, no VGPR round trip.  Address = uniform row base + per-lane 32-bit byte offset; M0 (the LDS destination base)
+// is written in the statement that uses it (gfx9 LDS instructions do not need it).  Round 5: the DMAs are issued by a
+// second wavefront of the workgroup (decode_prefetcher) -- in the decoding wave they were 7 of its ~45 instructions per
+// symbol (a lone wavefront issues one instruction per 4 cycles, whatever the kind: tools/lat_probe.hip).
 __device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
-// One stream, one wavefront.  PLANE: a CDF row serves `plane` consecutive symbols (factorised prior of z), else one
-// row per symbol.  Written for instruction count (the chain is serial by format): ~50 instructions per symbol on
-// the common path -- window read, two subtractions, one mad + shift, compare + popcount, the DMA of the window
-// DEC_D - 1 symbols ahead with its offset bump (add + min: parked on the last row, no counter), two readlanes, the
-// interval update, and renormalisation only when a leading bit is final (skipped otherwise: at < 1 bit per
-// symbol most symbols shift nothing).
+// One stream, one decoding wavefront (+ the prefetching one).  PLANE: a CDF row serves `plane` consecutive symbols
+// (factorised prior of z), else one row per symbol.  Written for what a lone wavefront pays (tools/lat_probe.hip: 4 cycles
+// per instruction of any kind, +24 per taken branch, +16..20 per VALU -> SALU crossing): per symbol a window read, two
+// subtractions, one mad + shift, compare + popcount, two readlanes, the interval update, ONE renormalisation test and,
+// when it fires, one merged shift; the loop is unrolled by hand, the window's answer is taken unconditionally and
+// replaced on the rare symbol outside the window.
 // WINDOWED: `rows` holds only the 64-entry window of every position (laplace_cdf_windows_kernel) and `sigma_pos` its
 // sigma: the slow path evaluates the entries it needs itself.
 template <bool PLANE, bool WINDOWED = false>
@@ -729,43 +728,23 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
   bw.lane = lane;
   bw.init();
   uint32_t low = 0, high = 0xFFFFFFFFu;
-  const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
   const uint32_t n_sym = st.n_sym, plane = st.plane;
-  const uint32_t n_rows = PLANE ? (n_sym + plane - 1u) / plane : n_sym;
   const uint16_t *base = rows + st.row_off * ROWLEN;
   auto row_of = [&](uint32_t i) -> const uint16_t * { return base + (uint64_t)(PLANE ? i / plane : i) * ROWLEN; };
-  // prefetcher: per-lane byte offset of its window entry in the row of the symbol being fetched (host side: a
-  // stream's rows span < 4 GiB)
-  uint32_t voff = (uint32_t)(WOFF + lane) * 2u;
-  const uint32_t vlast = voff + (n_rows - 1u) * (uint32_t)(ROWLEN * 2);
-  uint32_t pf_slot = 0, pf_in_plane = 0;
-  auto prefetch = [&]() {
-    window_dma(base, voff, ring_base + pf_slot);
-    pf_slot = (pf_slot + 256u) & (DEC_D * 256u - 1u);
-    uint32_t step = (uint32_t)(ROWLEN * 2);
-    if (PLANE) {
-      ++pf_in_plane;
-      const bool wrap = pf_in_plane == plane;
-      step = wrap ? step : 0u;
-      pf_in_plane = wrap ? 0u : pf_in_plane;
-    }
-    voff = min(voff + step, vlast);
-  };
-#pragma unroll 1
-  for (uint32_t i = 0; i < DEC_D; ++i) prefetch();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 1) : "memory");
-  uint32_t ew_next = ring[lane];  // window of symbol 0
-  uint32_t rd = 64u + (uint32_t)lane;
+  uint32_t ew_next = 0;
 
   uint32_t mysym = 0;
 #pragma unroll 1
-  for (uint32_t first = 0; first < n_sym; first += 64u) {
-    const uint32_t cnt = min(64u, n_sym - first);
+  for (uint32_t first = 0; first < n_sym; first += (uint32_t)DEC_HALF) {
+    const uint32_t cnt = min((uint32_t)DEC_HALF, n_sym - first);
+    __syncthreads();  // the prefetching wave has filled this block's half of the ring (and starts on the other one)
+    const uint32_t *hw = ring + ((first / DEC_HALF) & 1u) * (DEC_HALF * 64) + lane;
+    ew_next = hw[0];
     // the second half of a symbol step: record, interval update, renormalisation.  A lambda called from the fast AND
     // the slow path: as code after their join the compiler keeps a "came from the fast path" flag and tests it on
     // every symbol (a second branch per symbol)
     auto finish = [&](const uint32_t j, const uint32_t m, const uint32_t t_lo, const uint32_t t_hi) __attribute__((always_inline)) {
-      mysym = (uint32_t)lane == j ? m : mysym;
+      mysym = (uint32_t)lane == ((first + j) & 63u) ? m : mysym;
       // interval update (also after the last symbol: the state is dead then, reads past the payload are zeros)
       high = low + t_hi - 1u;
       low = low + t_lo;
@@ -790,18 +769,15 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
     // taken branch costs a lone wavefront 24 cycles per symbol)
     auto step = [&](const uint32_t j) __attribute__((always_inline)) {
       const uint32_t ew = ew_next;
-      // window of the next symbol (its DMA was issued DEC_D - 1 symbols ago): read now, used in the next
-      // iteration, so the LDS latency hides behind this symbol's arithmetic
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEC_D - 2) : "memory");
-      ew_next = ring[rd];
-      rd = (rd + 64u) & (DEC_D * 64u - 1u);
+      // window of the next symbol: read now, used in the next step, so the LDS latency hides behind this symbol's
+      // arithmetic (at a block's last symbol the slot belongs to the other half: read, never used)
+      ew_next = hw[(j + 1u) * 64u];
       const uint32_t hl = high - low;  // span - 1
       const uint32_t d = bw.value() - low;
       uint32_t m, t_lo, t_hi;
       // fast path: entries are strictly increasing, so the lanes with t <= d form a prefix
       const uint32_t tw = scaled(ew, hl);
       const uint32_t cw = (uint32_t)__builtin_popcountll(__ballot(tw <= d));
-      prefetch();  // after the use of `ew`: its LDS read has returned before the slot is handed to the next DMA
       // The window's answer is taken unconditionally (v_readlane uses the low 6 bits of its lane operand: any cw is a
       // valid read) and REPLACED on the rare symbol outside it: an if without else is one not-taken branch per symbol,
       // the if / else form made the compiler keep and test a "came from the fast path" flag as well
@@ -897,45 +873,91 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
     }
 #pragma unroll 1
     for (; j < cnt; ++j) step(j);
-    if ((uint32_t)lane < cnt) sym[st.out_off + first + lane] = (uint16_t)mysym;
+    // lane l holds symbol l of the 64-symbol group this block belongs to: stored when the group (or the stream) ends
+    const uint32_t g0 = first & ~63u, done = first + cnt;
+    if (((done & 63u) == 0u || done == n_sym) && (uint32_t)lane < done - g0) sym[st.out_off + g0 + lane] = (uint16_t)mysym;
   }
   // bits shifted in by renormalisation over the whole stream (the window was primed with 64 at word index 2)
   return bw.wi * 32u - bw.avail;
 }
 
-__global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t *__restrict__ bytes,
-                                                          const uint16_t *__restrict__ rows, aivc_rc_batch batch,
-                                                          uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
-  __shared__ uint32_t ring[DEC_D * 64];  // the DMA writes one dword per lane (a ushort load lands zero-extended at lane * 4)
+// The second wavefront of a decoding workgroup: LDS-DMA of the 64-entry windows, DEC_HALF symbols per barrier.
+template <bool PLANE, bool WINDOWED = false>
+__device__ __forceinline__ void decode_prefetcher(const uint16_t *__restrict__ rows, const aivc_rc_stream &st, uint32_t *ring,
+                                                  const int lane) {
+  constexpr int ROWLEN = WINDOWED ? CDF_WIN : AIVC_CDF_ROW;
+  constexpr int WOFF = WINDOWED ? 0 : DEC_WIN0;
+  const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
+  const uint32_t n_sym = st.n_sym, plane = st.plane;
+  const uint32_t n_rows = PLANE ? (n_sym + plane - 1u) / plane : n_sym;
+  const uint16_t *base = rows + st.row_off * ROWLEN;
+  // per-lane byte offset of its window entry in the row of the symbol being fetched (host side: a stream's rows span
+  // < 4 GiB); parked on the last row past the end of the stream (add + min, no counter)
+  uint32_t voff = (uint32_t)(WOFF + lane) * 2u;
+  const uint32_t vlast = voff + (n_rows - 1u) * (uint32_t)(ROWLEN * 2);
+  uint32_t in_plane = 0;
+#pragma unroll 1
+  for (uint32_t first = 0; first < n_sym; first += (uint32_t)DEC_HALF) {
+    const uint32_t half = ring_base + ((first / DEC_HALF) & 1u) * (DEC_HALF * 256);
+#pragma unroll 8
+    for (uint32_t k = 0; k < (uint32_t)DEC_HALF; ++k) {
+      window_dma(base, voff, half + k * 256u);
+      uint32_t step = (uint32_t)(ROWLEN * 2);
+      if (PLANE) {
+        ++in_plane;
+        const bool wrap = in_plane == plane;
+        step = wrap ? step : 0u;
+        in_plane = wrap ? 0u : in_plane;
+      }
+      voff = min(voff + step, vlast);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the half is complete (and no DMA outlives the workgroup's LDS)
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(128) void range_decode_kernel(const uint8_t *__restrict__ bytes,
+                                                           const uint16_t *__restrict__ rows, aivc_rc_batch batch,
+                                                           uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
+  __shared__ uint32_t ring[DEC_SLOTS * 64];  // the DMA writes one dword per lane (a ushort load lands zero-extended at lane * 4)
   const aivc_rc_stream st = batch.s[blockIdx.x];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (st.n_sym == 0) {
-    if (consumed && lane == 0) consumed[blockIdx.x] = 0;
+    if (consumed && threadIdx.x == 0) consumed[blockIdx.x] = 0;
     return;
   }
   __builtin_amdgcn_s_setprio(3);  // latency-critical serial wave (see range_encode_kernel)
+  if (wave == 1) {
+    if (st.plane) decode_prefetcher<true>(rows, st, ring, lane);
+    else decode_prefetcher<false>(rows, st, ring, lane);
+    return;
+  }
   uint32_t bits;
   if (st.plane) bits = decode_stream<true>(bytes, rows, st, sym, ring, lane);
   else bits = decode_stream<false>(bytes, rows, st, sym, ring, lane);
   if (consumed && lane == 0) consumed[blockIdx.x] = bits;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
-__global__ __launch_bounds__(64) void range_decode_windows_kernel(const uint8_t *__restrict__ bytes,
-                                                                  const uint16_t *__restrict__ win,
-                                                                  const float *__restrict__ sigma_pos, aivc_rc_batch batch,
-                                                                  uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
-  __shared__ uint32_t ring[DEC_D * 64];
+__global__ __launch_bounds__(128) void range_decode_windows_kernel(const uint8_t *__restrict__ bytes,
+                                                                   const uint16_t *__restrict__ win,
+                                                                   const float *__restrict__ sigma_pos, aivc_rc_batch batch,
+                                                                   uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
+  __shared__ uint32_t ring[DEC_SLOTS * 64];
   const aivc_rc_stream st = batch.s[blockIdx.x];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (st.n_sym == 0) {
-    if (consumed && lane == 0) consumed[blockIdx.x] = 0;
+    if (consumed && threadIdx.x == 0) consumed[blockIdx.x] = 0;
     return;
   }
   __builtin_amdgcn_s_setprio(3);  // (the convolutions' priority instead measured the same: 74.3 vs 74.0 fps at high rate)
+  if (wave == 1) {
+    decode_prefetcher<false, true>(win, st, ring, lane);
+    return;
+  }
   const uint32_t bits = decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_pos);
   if (consumed && lane == 0) consumed[blockIdx.x] = bits;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace aivc
@@ -1107,7 +1129,7 @@ AIVC_EXPORT int aivc_range_decode_windows(const uint8_t *bytes, const uint16_t *
     if (batch->s[i].in_off % 4 || batch->s[i].plane != 0) return AIVC_ERR_ARG;
     if (((uint64_t)batch->s[i].n_sym + 1) * (uint64_t)(CDF_WIN * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(range_decode_windows_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, win,
+  hipLaunchKernelGGL(range_decode_windows_kernel, dim3(batch->n_streams), dim3(128), 0, to_stream(stream), bytes, win,
                      sigma_pos, *batch, sym, consumed_bits);
   return check_launch("range_decode_windows");
 }
@@ -1123,7 +1145,7 @@ AIVC_EXPORT int aivc_range_decode(const uint8_t *bytes, const uint16_t *rows, co
     const uint64_t n_rows = batch->s[i].plane ? (batch->s[i].n_sym + batch->s[i].plane - 1) / batch->s[i].plane : batch->s[i].n_sym;
     if ((n_rows + 1) * (uint64_t)(AIVC_CDF_ROW * 2) >= 0x100000000ull) return AIVC_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(range_decode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bytes, rows,
+  hipLaunchKernelGGL(range_decode_kernel, dim3(batch->n_streams), dim3(128), 0, to_stream(stream), bytes, rows,
                      *batch, sym, consumed_bits);
   return check_launch("range_decode");
 }
