@@ -6,7 +6,8 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
+PREC_FP32, PREC_BF16X3 = 0, 1  # aivc_conv_params.precision
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -41,7 +42,7 @@ class ConvParams(C.Structure):
                 ('flags', C.c_int32),
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
                 ('gdn_beta', _f), ('gdn_gamma', _f),
-                ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('reserved2', C.c_int32)]
+                ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('precision', C.c_int32)]
 
 
 MAX_IMAGES = 3

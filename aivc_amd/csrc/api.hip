@@ -49,6 +49,7 @@ static int validate_conv(const aivc_conv_params *p) {
     if (p->gdn < 0 || p->gdn > 2 || p->mode == AIVC_MODE_GDN || p->mode == AIVC_MODE_IGDN) return AIVC_ERR_ARG;
     if (!p->gdn_beta || !p->gdn_gamma) return AIVC_ERR_ARG;
   }
+  if (p->precision != AIVC_PREC_FP32 && p->precision != AIVC_PREC_BF16X3) return AIVC_ERR_ARG;
   if (p->tail_c_out) {
     if (p->tail_c_out < 0 || !p->tail_w || p->mode != AIVC_MODE_CONV || p->gdn || p->mul) return AIVC_ERR_ARG;
   }
@@ -59,6 +60,10 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
+  // 1000 + the fp32 code with the bf16x3 tile (0 = 128x128, 2 = 256x64): the precision mode takes this launch
+  if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
+      aivc::conv2d_mfma_supported(*p))
+    return 1000 + 100 + 10 * (p->mode == AIVC_MODE_TCONV ? 1 : 0) + (p->c_out == 64 ? 2 : 0) + (p->gdn ? 50 : 0);
   if (p->tail_c_out) {
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_tail_supported(*p)) return AIVC_ERR_UNSUPPORTED;
     return aivc::conv2d_mfma_variant(*p);
@@ -87,6 +92,10 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   hipStream_t s = aivc::to_stream(stream);
+  // precision mode (never the default): the shapes it covers; everything else runs the fp32 contract
+  if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
+      aivc::conv2d_mfma_supported(*p))
+    return aivc::conv2d_bf16x3(*p, s);
   if (p->gdn) {  // fused (I)GDN exists on the MFMA path only
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p)) return AIVC_ERR_UNSUPPORTED;
     return aivc::conv2d_mfma(*p, s);

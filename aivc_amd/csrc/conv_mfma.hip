@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -65,10 +66,17 @@ __device__ __forceinline__ void glds16(const float *base, uint32_t voff, uint32_
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false>
-__global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1)))) void conv_mfma_kernel(MfmaArgs a) {
+// PREC: 0 = the fp32 arithmetic contract (v_mfma_f32_32x32x2_f32, fixed-order fmaf chains); 1 = "bf16x3" (round 5, a
+// precision MODE, never the default): every fp32 operand is split exactly into three bf16 terms x = h + m + l and a
+// product a * b is the six bf16 MFMA products h h', h m', m h', m m', h l', l h' with fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate per instruction) -- the dropped terms are below 2^-24 |a b|.
+// Same LDS image, loader, epilogues and fused phases; only the K loop's fragment reads and MFMAs differ.  Results are
+// NOT the contract's bits (other summation tree): parity per mode is reported by tests/test_gpu_precision.py.
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false, int PREC = 0>
+__global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1))))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(!TAIL || (MODE == AIVC_MODE_CONV && !FUSE && FASTK && BN == 64 && BN % BK == 0), "fused tail: conv, c_out 64");
+  static_assert(PREC == 0 || (GLDS && FASTK && !TAIL), "bf16x3: the LDS-DMA loop with c_in % 32 == 0");
   constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
   constexpr int UB = (BN * OCT + 255) / 256;  // ... for B
   constexpr bool B_FULL = (BN * OCT) % 256 == 0;  // every thread stages a B unit: no exec masking
@@ -512,6 +520,115 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
         }
       }
     };
+    if constexpr (PREC == 1) {
+      // ---- bf16x3 K loop: a K tile of 32 is two slabs of 16; a fragment = 8 consecutive k of one row (two 16-byte
+      // chunks), lanes 0-31 take k 0-7 of the slab, lanes 32-63 k 8-15 (the operand layout of the 32x32x16 MFMA).
+      // Per slab a wave splits its TM + TN raw fragments (44 vector instructions each) and issues 6 x TM x TN MFMAs.
+      // The two phases do not overlap on this part: a vector instruction costs the matrix pipe its 4 issue cycles whoever
+      // issues it (the law of round 2) -- dealing the split out behind the MFMAs in source order (volatile
+      // asm; hipcc's schedulers otherwise gather the splits in front of the MFMAs of a block whatever fences or
+      // sched_group_barrier ask) measured 133 instead of 143 TFLOP/s fp32-equivalent (experiments/r05.md 7).
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      struct Raw { float4 lo, hi; };       // k 0-3, k 4-7 of the lane's 8
+      struct Tri { u32x4 h, m, l; };       // the three bf16 terms, packed in k order
+      const char *a_rs[2][2], *b_rs[2][2];  // [slab][chunk of the pair]
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int off = ((4 * sl + 2 * (lane >> 5) + c) ^ sw) << 4;
+          a_rs[sl][c] = ring + (wm * TM * 32 + (lane & 31)) * ROWB + off;
+          b_rs[sl][c] = ring + BM * ROWB + (wn * TN * 32 + (lane & 31)) * ROWB + off;
+        }
+      Raw ra[2][TM], rb[2][TN];
+      auto read_slab = [&](auto SET, auto STAGE, auto SLAB) {
+        constexpr int set = decltype(SET)::value, stage = decltype(STAGE)::value, sl = decltype(SLAB)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ra[set][i].lo = *reinterpret_cast<const float4 *>(a_rs[sl][0] + stage * STAGE_B + i * 32 * ROWB);
+          ra[set][i].hi = *reinterpret_cast<const float4 *>(a_rs[sl][1] + stage * STAGE_B + i * 32 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          rb[set][j].lo = *reinterpret_cast<const float4 *>(b_rs[sl][0] + stage * STAGE_B + j * 32 * ROWB);
+          rb[set][j].hi = *reinterpret_cast<const float4 *>(b_rs[sl][1] + stage * STAGE_B + j * 32 * ROWB);
+        }
+      };
+      // x = h + m + l exactly (each term the bf16 nearest to what is left: 8 + 8 + 8 significant bits)
+      auto split2 = [](float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float u, float v) {
+          const bf16x2 t = __builtin_convertvector((f32x2){u, v}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
+          return __builtin_bit_cast(uint32_t, t);
+        };
+        h = pk(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
+        m = pk(r0, r1);
+        const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
+        l = pk(q0, q1);
+      };
+      auto split = [&](const Raw &r) {
+        uint32_t h[4], m[4], l[4];
+        split2(r.lo.x, r.lo.y, h[0], m[0], l[0]);
+        split2(r.lo.z, r.lo.w, h[1], m[1], l[1]);
+        split2(r.hi.x, r.hi.y, h[2], m[2], l[2]);
+        split2(r.hi.z, r.hi.w, h[3], m[3], l[3]);
+        return Tri{(u32x4){h[0], h[1], h[2], h[3]}, (u32x4){m[0], m[1], m[2], m[3]}, (u32x4){l[0], l[1], l[2], l[3]}};
+      };
+      auto mm = [&](floatx16 &c, const u32x4 &x, const u32x4 &y) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+      };
+      auto slab_mfmas = [&](auto SET) {
+        constexpr int set = decltype(SET)::value;
+        Tri ta[TM], tb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ta[i] = split(ra[set][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tb[j] = split(rb[set][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {  // small terms first
+            mm(acc[i][j], ta[i].l, tb[j].h);
+            mm(acc[i][j], ta[i].h, tb[j].l);
+            mm(acc[i][j], ta[i].m, tb[j].m);
+            mm(acc[i][j], ta[i].m, tb[j].h);
+            mm(acc[i][j], ta[i].h, tb[j].m);
+            mm(acc[i][j], ta[i].h, tb[j].h);
+          }
+      };
+      using std::integral_constant;
+      using J0 = integral_constant<int, 0>;
+      using J1 = integral_constant<int, 1>;
+      auto body_bf = [&](auto STAGE, int kt) {
+        constexpr int stage = decltype(STAGE)::value;
+        using NEXT = integral_constant<int, 1 - stage>;
+        read_slab(J1{}, STAGE, J1{});   // slab 1 of this tile on its way
+        slab_mfmas(J0{});               // slab 0 (read at the end of the previous tile)
+        if (kt + 1 < nkt) {
+          // every read of this stage is in registers, this wave's DMAs (and zero fills) of tile kt + 1 have landed ...
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();  // ... and everybody else's
+          read_slab(J0{}, NEXT{}, J0{});
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (kt + 2 < nkt) issue_tile(stage);
+        slab_mfmas(J1{});
+      };
+      issue_tile(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (nkt > 1) issue_tile(1);
+      read_slab(J0{}, J0{}, J0{});
+      for (int kt = 0; kt < nkt; kt += 2) {
+        body_bf(J0{}, kt);
+        if (kt + 1 < nkt) body_bf(J1{}, kt + 1);
+      }
+      __syncthreads();  // the ring is reused (padded layout) by the fused phases below
+    } else {
     using std::integral_constant;
     using I0 = integral_constant<int, 0>;
     using I1 = integral_constant<int, 1>;
@@ -574,6 +691,7 @@ __global__ __launch_bounds__(256, (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : 
     }
 #undef AIVC_SB
     __syncthreads();  // the ring is reused (padded layout) by the fused phases below
+    }  // PREC
   } else {
   load_tile(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -1098,7 +1216,7 @@ extern "C" __attribute__((visibility("default"))) int aivc_dbg_dump(unsigned lon
 }
 #endif
 
-template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false, int PREC = 0>
 static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   MfmaArgs a;
@@ -1116,13 +1234,14 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
   if (lds > 64 * 1024) {
     static LdsOptIn opt_in;  // per instantiation, per device
-    if (!opt_in.raise(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), lds))
+    if (!opt_in.raise(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS, PREC>), lds))
       return check_launch("conv_mfma lds attribute");
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS, PREC>), grid, dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
+#ifndef AIVC_CONV_BF16X3
 // LDS-DMA K loop: conv with c_in % 32 == 0 on the tiles it is instantiated for; per-lane BYTE offsets are 32 bits
 static bool use_glds(const aivc_conv_params &p) {
   static const int off = getenv("AIVC_NO_GLDS") ? atoi(getenv("AIVC_NO_GLDS")) : 0;  // tuning aid: 1 = the register-staged loop everywhere, 2 = for transposed conv
@@ -1310,5 +1429,53 @@ int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
     default: return AIVC_ERR_UNSUPPORTED;
   }
 }
+
+#else  // AIVC_CONV_BF16X3: this translation unit (conv_bf16x3.hip includes this file) holds the bf16x3 instantiations only
+
+// The precision mode covers the layers that carry the FLOPs: conv / transposed conv with c_in % 32 == 0 and c_out of 64
+// or a multiple of 128, with or without fused (I)GDN (its second GEMM stays fp32), no fused 1x1 tail.  Wave tile 64x64
+// (128x128 / 256x64 workgroup tiles): the six products of a 64x64x16 slab are 24 MFMAs of 32 cycles against ~180 vector
+// instructions of operand splitting -- smaller wave tiles are bound by the splitting.
+bool conv2d_bf16x3_supported(const aivc_conv_params &p) {
+  if (p.mode != AIVC_MODE_CONV && p.mode != AIVC_MODE_TCONV) return false;
+  if (p.tail_c_out || p.c_in % BK != 0) return false;
+  if (p.c_out != 64 && p.c_out % 128 != 0) return false;
+  if (p.gdn && p.c_out != 64 && p.c_out != 128) return false;
+  // short reductions (the 1x1 convs: two to four K tiles) are prologue / epilogue work on the mode's big tiles: they stay
+  // on the fp32 kernels' small tiles (measured: 109-121 TFLOP/s fp32-equivalent against 125-133 there)
+  const int taps = p.mode == AIVC_MODE_TCONV ? (p.ksize * p.ksize + 3) / 4 : p.ksize * p.ksize;
+  if (taps * p.c_in < 512) return false;
+  if ((uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 4ull >= 0xFFFFFFFFull || (uint64_t)p.ksize * p.ksize * p.c_in >= 65536ull) return false;
+  return (uint64_t)p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFF0ull;  // one image inside the loader's 32-bit byte offsets
+}
+
+template <int MODE>
+static int launch_bf16x3(const aivc_conv_params &p, hipStream_t s) {
+  if (p.c_out == 64) return p.gdn ? launch_cfg2<MODE, 4, 1, 2, 2, true, true, false, true, 1>(p, s)
+                                  : launch_cfg2<MODE, 4, 1, 2, 2, false, true, false, true, 1>(p, s);
+  return p.gdn ? launch_cfg2<MODE, 2, 2, 2, 2, true, true, false, true, 1>(p, s)
+               : launch_cfg2<MODE, 2, 2, 2, 2, false, true, false, true, 1>(p, s);
+}
+
+int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s) {
+  if (!conv2d_bf16x3_supported(p)) return AIVC_ERR_UNSUPPORTED;
+  // a batch beyond the 4 GB the loader addresses goes out as sub-batches (images are independent)
+  const uint64_t per_image = (uint64_t)p.h_in * p.w_in * p.c_in * 4ull;
+  const int chunk = (int)(0xFFFFFFF0ull / per_image);
+  for (int n0 = 0; n0 < p.n; n0 += chunk) {
+    aivc_conv_params q = p;
+    q.n = p.n - n0 < chunk ? p.n - n0 : chunk;
+    const size_t in_off = (size_t)n0 * p.h_in * p.w_in * p.c_in, out_off = (size_t)n0 * p.h_out * p.w_out * p.c_out;
+    q.x = p.x + in_off;
+    q.y = p.y + out_off;
+    if (p.res) q.res = p.res + out_off;
+    if (p.mul) q.mul = p.mul + out_off;
+    const int rc = p.mode == AIVC_MODE_CONV ? launch_bf16x3<AIVC_MODE_CONV>(q, s) : launch_bf16x3<AIVC_MODE_TCONV>(q, s);
+    if (rc) return rc;
+  }
+  return AIVC_OK;
+}
+
+#endif  // AIVC_CONV_BF16X3
 
 }  // namespace aivc

@@ -97,6 +97,24 @@ def pack_weight(w, c_store=None, transposed=False):
     return w.contiguous().float()
 
 
+PRECISION = abi.PREC_FP32  # see set_precision()
+
+
+def set_precision(mode):
+    """'fp32' (default): the arithmetic contract -- HIP == CPU oracle bit for bit, bitstreams reproducible on every GPU.
+    'bf16x3': the precision MODE of the wide convolutions (include/aivc_hip.h, aivc_conv_params.precision): fp32 operands
+    as three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation.  Results are within fp32
+    summation-order noise of the contract's, not its bits: an encoder and a decoder must run the same mode.
+    -> the previous mode's name.  Process-wide (the codec's side streams read it too)."""
+    global PRECISION
+    names = {'fp32': abi.PREC_FP32, 'bf16x3': abi.PREC_BF16X3}
+    if mode not in names:
+        raise ValueError('precision %r: expected one of %s' % (mode, sorted(names)))
+    prev = [k for k, v in names.items() if v == PRECISION][0]
+    PRECISION = names[mode]
+    return prev
+
+
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
            res=None, algo=abi.ALGO_AUTO, gdn=None, tail=None):
     """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h).
@@ -144,6 +162,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
         g_beta, g_gamma, g_inv = gdn
         p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 2 if g_inv else 1, flags,
                            _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(g_beta), _p(g_gamma))
+        p.precision = PRECISION
         from ._lib import load
         if load()['aivc_conv2d_variant'](C.byref(p)) < 0:  # not fusable for this shape: two launches
             t = conv2d(x, w_ohwi, bias, mode=mode, stride=stride, pad=pad, algo=algo)
@@ -152,6 +171,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     else:
         p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, flags,
                            _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), None, None)
+    p.precision = PRECISION
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
         return y

@@ -57,6 +57,8 @@ def variant_name(v):
         return 'thin_mfma_kernel'
     if v == 190:
         return 'conv_mfma<conv,128x64+tail1x1>'
+    if v >= 1000:
+        return 'bf16x3:' + variant_name(v - 1000)
     if v == 191:
         return 'conv_images<4x32px,64+gdn>'
     c = v - 100
@@ -251,6 +253,8 @@ def main():
     ap.add_argument('--entropy-lookahead', type=int, default=0, help='decoder: dependency levels of entropy decoding issued ahead (0: the whole clip up front)')
     ap.add_argument('--no-high-rate', action='store_true', help='skip the high-rate operating point (every y feature map coded) measured after the headline run')
     ap.add_argument('--high-rate-steps', type=int, default=3)
+    ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
+    ap.add_argument('--precision-steps', type=int, default=2)
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -571,6 +575,56 @@ def main():
                              'networks is coded: each frame carries two serial range-coder streams of h_y*w_y*%d symbols' % c_y}
         del model_hr, fc_hr
 
+    # ---- the bf16x3 precision MODE (aivc_conv_params.precision; never the headline: `value` stays the fp32 contract):
+    # same clip, same model, same code path with the wide convolutions on six bf16 MFMA products per fp32 product
+    precision_mode = None
+    if rank == 0 and world == 1 and not args.no_precision_mode:
+        prev_prec = ops.set_precision('bf16x3')
+        try:
+            with torch.no_grad():
+                blobs, enc_recs, dd = fc.encode_units(clips[0], args.gop)
+                dec = fc.decode_units(blobs, dd, dev)
+                pm_closed = all(torch.equal(d[k], e[k]) for du, eu in zip(dec, enc_recs) for d, e in zip(du, eu) for k in 'yuv')
+                pm_errs = len(fc.stream_errors())
+                del dec, enc_recs
+                ops.PROFILE = []
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for i in range(args.precision_steps):
+                    blobs, _, dd = fc.encode_units(clips[(args.warmup + i) % len(clips)], args.gop)
+                    fc.decode_units(blobs, dd, dev)
+                torch.cuda.synchronize()
+                el_pm = time.time() - t0
+            per = {}
+            for variant, flops, e0, e1, _shape in ops.PROFILE:
+                d = per.setdefault(variant, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += flops
+                d[2] += e0.elapsed_time(e1) * 1e-3
+            ops.PROFILE = None
+            bf = {v: d for v, d in per.items() if v >= 1000}
+            fp = {v: d for v, d in per.items() if 100 <= v < 1000}
+        finally:
+            ops.set_precision(prev_prec)
+        precision_mode = {
+            'dtype': 'bf16x3', 'value': round(args.precision_steps * args.frames / el_pm, 4), 'unit': 'frames/s',
+            'steps': args.precision_steps, 'ms_per_step': round(el_pm / args.precision_steps * 1e3, 2),
+            'vs_headline': round(args.precision_steps * args.frames / el_pm / (clips_done_for_hr / elapsed), 4),
+            'closed_loop_ok': bool(pm_closed), 'stream_errors': pm_errs,
+            # algorithmic fp32-equivalent FLOPs (2 per multiply-add of the layer, as for the fp32 kernels) over HIP-event
+            # time; each fp32 product is six bf16 MFMA products, priced against the dense bf16 peak / 6
+            'bf16x3_kernels': {'launches': sum(d[0] for d in bf.values()), 'ms_per_step': round(sum(d[2] for d in bf.values()) / args.precision_steps * 1e3, 2),
+                               'fp32_equivalent_tflops': round(sum(d[1] for d in bf.values()) / max(sum(d[2] for d in bf.values()), 1e-9) / 1e12, 2),
+                               'peak_fp32_equivalent_tflops': round(2500.0 / 6.0, 1),
+                               'per_variant': {VARIANT_NAMES.get(v, str(v)): {'launches': d[0], 'fp32_equivalent_tflops': round(d[1] / d[2] / 1e12, 2),
+                                                                              'ms_total': round(d[2] * 1e3, 2)} for v, d in sorted(bf.items())}},
+            'fp32_contract_kernels_left': {'launches': sum(d[0] for d in fp.values()), 'ms_per_step': round(sum(d[2] for d in fp.values()) / args.precision_steps * 1e3, 2)},
+            'note': 'precision MODE, not the headline: fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per '
+                    'fp32 product, fp32 accumulation, for the conv / transposed conv layers with c_in % 32 == 0 and c_out of 64 / 128 '
+                    '(the image layers, the thin output layer, the fused 1x1 tail and the GDN GEMMs stay on the fp32 contract); '
+                    'within fp32 summation-order noise of the contract, not its bits (tests/test_gpu_precision.py); encoder and '
+                    'decoder must run the same mode'}
+
     if rank == 0:
         # N = 1: strong and weak are the same single-process run, the label says so
         scaling = 'single' if world == 1 else ('strong' if strong else 'weak')
@@ -611,7 +665,7 @@ def main():
             # bytes are unpinned here (no wheel in the image)
             'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate,
+            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate, 'precision_mode': precision_mode,
         }
         if other is not None:
             out['weak_scaling'] = other

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 11
+#define AIVC_ABI_VERSION 12
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -117,8 +117,15 @@ typedef struct aivc_conv_params {
   const float *tail_w;    /* [tail_c_out][c_out] */
   const float *tail_bias; /* [tail_c_out] or NULL */
   int32_t tail_c_out;
-  int32_t reserved2;
+  int32_t precision; /* AIVC_PREC_FP32 (0): the arithmetic contract above -- bit identical on every kernel and on the CPU
+                      * oracle.  AIVC_PREC_BF16X3 (1, ABI 12): a precision MODE for CONV / TCONV with c_in % 32 == 0 and c_out
+                      * of 64 or a multiple of 128 (other shapes run the fp32 contract): every fp32 operand is split exactly
+                      * into three bf16 terms and a product is six bf16 MFMA products with fp32 accumulation -- within fp32
+                      * summation-order noise of the contract's result but NOT its bits (tests/test_gpu_precision.py reports
+                      * the error per layer class).  Never the default; bitstreams of the two modes do not interoperate. */
 } aivc_conv_params;
+#define AIVC_PREC_FP32 0
+#define AIVC_PREC_BF16X3 1
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
  *                     s_i = fmaf chain over j (in AIVC_K_ORDER) of (t_j, gamma[i][j]) from +0, then + beta[i];

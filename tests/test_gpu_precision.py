@@ -1,0 +1,187 @@
+"""The bf16x3 precision MODE of the wide convolutions (include/aivc_hip.h: aivc_conv_params.precision; SURVEY.md section 7
+"expose precision as a mode and report parity per mode").  Never the default and never the headline: fp32 operands split
+exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation.  What is checked per mode:
+
+  * every covered layer shape against an fp64 evaluation of the same layer: the mode's error next to the fp32 contract's
+    (both are summation-order noise of an fp32 accumulator; the mode must stay within a small factor of the contract);
+  * the reference's own outputs at the hot-path widths (tests/golden/wide_*.npz), same bound as the fp32 kernels';
+  * the codec in this mode: encoder and decoder agree bit for bit on one GPU (closed loop, clean range-decoder bit count);
+  * the reconstruction of the SAME latents by the two modes: 8-bit planes within +-1 LSB;
+  * shapes the mode does not cover run the fp32 contract unchanged (bit identical to the default)."""
+import numpy as np
+import pytest
+import torch
+
+from aivc_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = [  # mode, k, stride, pad, c_in, c_out, h, w, fused gdn (0 / 1 / 2), residual
+    (abi.MODE_CONV, 5, 2, 2, 64, 128, 68, 120, 1, False),   # the dominant layer: 5x5 s2 64 -> 128 + GDN
+    (abi.MODE_CONV, 3, 1, 1, 128, 128, 34, 60, 0, True),    # residual block 3x3
+    (abi.MODE_CONV, 5, 2, 2, 128, 64, 34, 60, 0, False),    # last analysis conv, c_out 64 (256x64 tile)
+    (abi.MODE_CONV, 3, 1, 1, 64, 128, 17, 30, 0, False),    # 3x3 from 64 channels
+    (abi.MODE_TCONV, 5, 2, 0, 128, 128, 17, 30, 2, False),  # transposed 5x5 + inverse GDN
+    (abi.MODE_TCONV, 3, 2, 0, 128, 64, 19, 23, 0, False),   # transposed 3x3 to 64 channels, odd sizes
+]
+
+
+def _torch_fp64(mode, x, w, b, stride, pad, k):
+    """fp64 evaluation of the layer on the CPU (NHWC in / out): conv with replicate padding, or ConvTranspose2d k, s 2,
+    pad (1 + k) / 2 - 1, output_padding 1 (src/layers/misc/custom_conv_layers.py:129-253)"""
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w).double()  # OHWI
+    if mode == abi.MODE_CONV:
+        xp = F.pad(xt, (pad, pad, pad, pad), mode='replicate') if pad else xt
+        y = F.conv2d(xp, wt.permute(0, 3, 1, 2), torch.from_numpy(b).double(), stride=stride)
+    else:
+        y = F.conv_transpose2d(xt, wt.permute(3, 0, 1, 2), torch.from_numpy(b).double(), stride=2,
+                               padding=int((1 + k) / 2 - 1), output_padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('case', LAYERS)
+def test_layer_error_against_fp64(case, cuda):
+    from aivc_amd import ops
+    mode, k, s, pad, ci, co, h, w, gdn, use_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((2, h, w, ci), dtype=np.float32)
+    wt = (rng.standard_normal((co, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.standard_normal(co, dtype=np.float32)
+    ref = _torch_fp64(mode, x, wt, b, s, pad, k)
+    g = None
+    if gdn:
+        beta = (np.abs(rng.standard_normal(co)) + 0.5).astype(np.float32)
+        gamma = (np.abs(rng.standard_normal((co, co))) * 0.02).astype(np.float32)
+        nrm = torch.sqrt(torch.from_numpy(beta).double() + (ref * ref) @ torch.from_numpy(gamma).double().t())
+        ref = ref * nrm if gdn == 2 else ref / nrm
+        g = (torch.from_numpy(beta).to(cuda), torch.from_numpy(gamma).to(cuda), gdn == 2)
+    res = None
+    if use_res:
+        res = rng.standard_normal(tuple(ref.shape), dtype=np.float32)
+        ref = ref + torch.from_numpy(res).double()
+    ref = ref.numpy()
+    scale = np.sqrt(np.mean(ref * ref))
+    err = {}
+    for name in ('fp32', 'bf16x3'):
+        prev = ops.set_precision(name)
+        try:
+            y = ops.conv2d(torch.from_numpy(x).to(cuda), torch.from_numpy(wt).to(cuda), torch.from_numpy(b).to(cuda), mode=mode,
+                           stride=s, pad=pad, gdn=g, res=None if res is None else torch.from_numpy(res).to(cuda))
+        finally:
+            ops.set_precision(prev)
+        d = y.cpu().numpy().astype(np.float64) - ref
+        err[name] = (float(np.abs(d).max() / scale), float(np.sqrt(np.mean(d * d)) / scale))
+    print('\n%s k%d s%d %d->%d gdn%d: fp32 max %.2e rms %.2e | bf16x3 max %.2e rms %.2e' % (
+        'tconv' if mode == abi.MODE_TCONV else 'conv', k, s, ci, co, gdn, *err['fp32'], *err['bf16x3']))
+    # fp32 accumulation noise for K up to 3200 terms is ~1e-7 rms of the output scale; the mode may not be worse than a
+    # few times the contract's own distance from the fp64 value
+    assert err['bf16x3'][1] <= max(4.0 * err['fp32'][1], 2e-7), err
+    assert err['bf16x3'][0] <= max(4.0 * err['fp32'][0], 2e-6), err
+
+
+def test_mode_takes_the_covered_shapes_only(cuda):
+    """aivc_conv2d_variant says which kernel a launch takes: 1000 + code for the precision mode; a layer the mode does not
+    cover (thin output, image layer, c_out 32, fused 1x1 tail) runs the fp32 contract: bit identical to the default"""
+    from aivc_amd import ops
+    from aivc_amd._lib import load
+    import ctypes as C
+    rng = np.random.default_rng(3)
+
+    def variant(mode, k, s, pad, ci, co, h, w, prec):
+        ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+        x = torch.zeros((1, h, w, ci), device=cuda)
+        wt = torch.zeros((co, k, k, ci), device=cuda)
+        y = torch.zeros((1, ho, wo, co), device=cuda)
+        p = abi.ConvParams(mode, k, s, pad, 1, h, w, ci, ho, wo, co, 0, 0, abi.ALGO_AUTO, 0, 0, x.data_ptr(), wt.data_ptr(), None,
+                           None, None, y.data_ptr(), None, None)
+        p.precision = prec
+        return load()['aivc_conv2d_variant'](C.byref(p))
+    assert variant(abi.MODE_CONV, 3, 1, 1, 128, 128, 34, 60, abi.PREC_BF16X3) == 1100
+    assert variant(abi.MODE_CONV, 5, 2, 2, 128, 64, 34, 60, abi.PREC_BF16X3) == 1102
+    assert variant(abi.MODE_TCONV, 5, 2, 0, 128, 128, 17, 30, abi.PREC_BF16X3) == 1110
+    assert variant(abi.MODE_CONV, 3, 1, 1, 128, 128, 34, 60, abi.PREC_FP32) < 1000
+    for shape in ((abi.MODE_CONV, 3, 1, 1, 128, 32, 20, 20), (abi.MODE_CONV, 5, 2, 2, 8, 64, 40, 40), (abi.MODE_TCONV, 5, 2, 0, 64, 3, 20, 20),
+                  (abi.MODE_CONV, 1, 1, 0, 128, 64, 20, 20)):  # (1x1: reduction too short for the mode's tiles)
+        assert variant(*shape, abi.PREC_BF16X3) < 1000
+        mode, k, s, pad, ci, co, h, w = shape
+        x = torch.from_numpy(rng.standard_normal((1, h, w, ci), dtype=np.float32)).to(cuda)
+        wt = torch.from_numpy(rng.standard_normal((co, k, k, ci), dtype=np.float32) * 0.05).to(cuda)
+        a = ops.conv2d(x, wt, None, mode=mode, stride=s, pad=pad)
+        prev = ops.set_precision('bf16x3')
+        try:
+            b = ops.conv2d(x, wt, None, mode=mode, stride=s, pad=pad)
+        finally:
+            ops.set_precision(prev)
+        assert torch.equal(a, b)
+
+
+def test_wide_reference_fixtures_in_bf16x3(cuda, golden):
+    """the reference's own outputs at the hot-path widths (tests/golden/wide_*.npz): the mode meets the bound the fp32
+    kernels are held to (2e-5 relative to max(1, |y|)); the error of each case is printed next to the fp32 kernels'"""
+    from test_wide_golden import NAMES, _build, _run_gpu
+    from aivc_amd import ops
+    worst = {}
+    took = set()
+    for name in NAMES:
+        g = golden('wide_' + name)
+        m, x, _ = _build(name)
+        errs = []
+        for mode in ('fp32', 'bf16x3'):
+            prev = ops.set_precision(mode)
+            try:
+                y, variants = _run_gpu(m, x, cuda)
+            finally:
+                ops.set_precision(prev)
+            errs.append(float((np.abs(y - g['y']) / np.maximum(1.0, np.abs(g['y']))).max()))
+            if mode == 'bf16x3':
+                took |= {v for v in variants if v >= 1000}
+        worst[name] = errs
+    print('\nmax relative error vs the reference outputs, fp32 | bf16x3:')
+    for k, (e0, e1) in worst.items():
+        print('  %-22s %.2e | %.2e' % (k, e0, e1))
+    assert took, 'no launch of these cases took the precision mode'
+    assert max(e[1] for e in worst.values()) <= 2e-5, worst
+
+
+def test_codec_closed_loop_and_cross_mode_reconstruction(cuda):
+    """default-width model, 416x240, 9 frames RA: in bf16x3 mode the decoder reproduces the encoder's reconstruction bit
+    for bit and every range-decoder stream ends where its payload ends; the SAME latents reconstructed by the two modes
+    give 8-bit planes within +-1 LSB"""
+    from aivc_amd import ops, synth
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.models import arch
+    model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+    synth.calibrate_operating_point(model, cuda)
+    frames = synth.to_device_frames(synth.synthetic_video(416, 240, 9, seed=9), cuda)
+    fc = FrameCodec(model)
+    prev = ops.set_precision('bf16x3')
+    try:
+        with torch.no_grad():
+            enc = fc.encode_video(frames, '1_GOP_8')
+            blob = fc.assemble_video(enc)
+            dec, _, _, _ = fc.decode_video(blob, cuda)
+        assert fc.stream_errors() == []
+        rec = [r for g in enc['recs'] for r in g][:len(dec)]
+        for i, (d, e) in enumerate(zip(dec, rec)):
+            for k in 'yuv':
+                assert torch.equal(d[k], e[k]), (i, k)
+    finally:
+        ops.set_precision(prev)
+    # the same I-frame latents through the synthesis of both modes
+    with torch.no_grad():
+        out = fc.encode_batch([frames[0]], [None], [None], 0)
+        from aivc_amd.real_life.bitstream import finalize_frames
+        fb = finalize_frames(out['sections'])
+        yh = fc.entropy_decode(fb, 0, out['data_dim'], device=cuda)
+        a = fc.synthesise_batch(yh, [None], [None], 0, out['data_dim'])[0]
+        prev = ops.set_precision('bf16x3')
+        try:
+            b = fc.synthesise_batch(yh, [None], [None], 0, out['data_dim'])[0]
+        finally:
+            ops.set_precision(prev)
+    diff = {k: (a[k].int() - b[k].int()).abs() for k in 'yuv'}
+    frac = sum(int((v > 0).sum()) for v in diff.values()) / sum(v.numel() for v in diff.values())
+    print('\nsame latents, fp32 vs bf16x3 synthesis: %.4f %% of the 8-bit samples differ (by 1 LSB)' % (100 * frac))
+    assert max(int(v.max()) for v in diff.values()) <= 1
