@@ -712,12 +712,14 @@ __device__ __forceinline__ void window_dma(const uint16_t *base, uint32_t voff, 
 // subtractions, one mad + shift, compare + popcount, two readlanes, the interval update, ONE renormalisation test and,
 // when it fires, one merged shift; the loop is unrolled by hand, the window's answer is taken unconditionally and
 // replaced on the rare symbol outside the window.
-// WINDOWED: `rows` holds only the 64-entry window of every position (laplace_cdf_windows_kernel) and `sigma_pos` its
-// sigma: the slow path evaluates the entries it needs itself.
+// WINDOWED: `rows` holds only the 64-entry window of every position (laplace_cdf_windows_kernel); the slow path evaluates
+// the entries it needs itself from the position's Laplace scale, which the prefetching wave has put beside the windows
+// (`sigma_ring`, LDS).  At high rate a quarter of an I frame's symbols take that path and it is a serial chain of
+// ~100 fp64 / fp32 instructions: aivc_laplace_cdf_u16_scale is the row function laid out without divergent branches.
 template <bool PLANE, bool WINDOWED = false>
 __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ bytes, const uint16_t *__restrict__ rows,
                                               const aivc_rc_stream &st, uint16_t *__restrict__ sym, uint32_t *ring,
-                                              const int lane, const float *__restrict__ sigma_pos = nullptr) {
+                                              const int lane, const float *sigma_ring = nullptr) {
   static_assert(!(PLANE && WINDOWED), "windows are per-position Laplace rows");
   constexpr int ROWLEN = WINDOWED ? CDF_WIN : AIVC_CDF_ROW;  // uint16 entries per stored row
   constexpr int WOFF = WINDOWED ? 0 : DEC_WIN0;              // position of the window inside a stored row
@@ -795,15 +797,19 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
           // 64 if it is not there.  (Round 4 rebuilt the whole row in two dependent evaluation passes -- every 8th entry,
           // then the octet: twice the fp64 work on the common near miss; I-frame streams at high rate take this path on
           // a quarter of their symbols.)  m = (entries 0 .. 511 with t <= d) - 1, as the full-row search defines it.
-          const float sg = sigma_pos[st.row_off + i];
+          // (the Laplace scale b = sigma / sqrt(2) of the position: the division is done by the prefetching wave)
+          const float sg = sigma_ring[((first / DEC_HALF) & 1u) * DEC_HALF + j];
           if (cw == 0u) {
             uint32_t above = rl(tw, 0);  // t of the entry right above the block being searched
             int base = DEC_WIN0 - 64;
 #pragma unroll 1
             for (;;) {
-              const uint32_t tf = scaled((uint32_t)aivc_laplace_cdf_u16(base + lane, sg), hl);
-              const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(tf <= d));
-              if (c > 0u) {  // (entry 0 is 0 <= d: the block at base 0 always ends the search)
+              const uint32_t tf = scaled((uint32_t)aivc_laplace_cdf_u16_scale(base + lane, sg), hl);
+              uint32_t c = (uint32_t)__builtin_popcountll(__ballot(tf <= d));
+              // (the block at base 0 ends the search whatever it holds: a corrupt stream can ask for less than entry 0
+              // when sigma is large enough for entry 0 to be non-zero; the full-row search answers symbol 0 then)
+              if (base == 0) c = max(c, 1u);
+              if (c > 0u) {
                 m = (uint32_t)base + c - 1u;
                 t_lo = rl(tf, (int)c - 1);
                 t_hi = c < 64u ? rl(tf, (int)c) : above;
@@ -818,7 +824,7 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
 #pragma unroll 1
             for (;;) {
               const int k = base + lane;  // entries up to 512 exist (512 = lower bound of symbol 512); 0 .. 511 count
-              const uint32_t tf = scaled((uint32_t)aivc_laplace_cdf_u16(min(k, AIVC_MAX_SYMBOL), sg), hl);
+              const uint32_t tf = scaled((uint32_t)aivc_laplace_cdf_u16_scale(min(k, AIVC_MAX_SYMBOL), sg), hl);
               const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(k < AIVC_MAX_SYMBOL && tf <= d));
               if (c < 64u) {  // (the block holding entry 511 has c <= 32)
                 m = (uint32_t)base + c - 1u;
@@ -884,7 +890,8 @@ __device__ __forceinline__ uint32_t decode_stream(const uint8_t *__restrict__ by
 // The second wavefront of a decoding workgroup: LDS-DMA of the 64-entry windows, DEC_HALF symbols per barrier.
 template <bool PLANE, bool WINDOWED = false>
 __device__ __forceinline__ void decode_prefetcher(const uint16_t *__restrict__ rows, const aivc_rc_stream &st, uint32_t *ring,
-                                                  const int lane) {
+                                                  const int lane, const float *__restrict__ sigma_pos = nullptr,
+                                                  float *sigma_ring = nullptr) {
   constexpr int ROWLEN = WINDOWED ? CDF_WIN : AIVC_CDF_ROW;
   constexpr int WOFF = WINDOWED ? 0 : DEC_WIN0;
   const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)ring;
@@ -899,6 +906,9 @@ __device__ __forceinline__ void decode_prefetcher(const uint16_t *__restrict__ r
 #pragma unroll 1
   for (uint32_t first = 0; first < n_sym; first += (uint32_t)DEC_HALF) {
     const uint32_t half = ring_base + ((first / DEC_HALF) & 1u) * (DEC_HALF * 256);
+    float sg = 1.f;
+    if constexpr (WINDOWED)  // the block's sigmas, one per lane, for the decoding wave's slow path
+      sg = sigma_pos[st.row_off + min(first + (uint32_t)(lane & (DEC_HALF - 1)), n_sym - 1u)];
 #pragma unroll 8
     for (uint32_t k = 0; k < (uint32_t)DEC_HALF; ++k) {
       window_dma(base, voff, half + k * 256u);
@@ -912,6 +922,8 @@ __device__ __forceinline__ void decode_prefetcher(const uint16_t *__restrict__ r
       voff = min(voff + step, vlast);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the half is complete (and no DMA outlives the workgroup's LDS)
+    if constexpr (WINDOWED)
+      if (lane < DEC_HALF) sigma_ring[((first / DEC_HALF) & 1u) * DEC_HALF + lane] = aivc_laplace_scale(sg);
     __syncthreads();
   }
 }
@@ -944,6 +956,7 @@ __global__ __launch_bounds__(128) void range_decode_windows_kernel(const uint8_t
                                                                    const float *__restrict__ sigma_pos, aivc_rc_batch batch,
                                                                    uint16_t *__restrict__ sym, uint32_t *__restrict__ consumed) {
   __shared__ uint32_t ring[DEC_SLOTS * 64];
+  __shared__ float sigma_ring[2 * DEC_HALF];
   const aivc_rc_stream st = batch.s[blockIdx.x];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -953,10 +966,10 @@ __global__ __launch_bounds__(128) void range_decode_windows_kernel(const uint8_t
   }
   __builtin_amdgcn_s_setprio(3);  // (the convolutions' priority instead measured the same: 74.3 vs 74.0 fps at high rate)
   if (wave == 1) {
-    decode_prefetcher<false, true>(win, st, ring, lane);
+    decode_prefetcher<false, true>(win, st, ring, lane, sigma_pos, sigma_ring);
     return;
   }
-  const uint32_t bits = decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_pos);
+  const uint32_t bits = decode_stream<false, true>(bytes, win, st, sym, ring, lane, sigma_ring);
   if (consumed && lane == 0) consumed[blockIdx.x] = bits;
 }
 

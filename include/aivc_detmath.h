@@ -46,11 +46,8 @@ AIVC_HD uint64_t aivc_f64_to_bits(double d) {
 /* 2^k for -1022 <= k <= 1023 */
 AIVC_HD double aivc_pow2i(int k) { return aivc_bits_to_f64((uint64_t)(k + 1023) << 52); }
 
-/* exp(x), |rel err| < ~2 ulp(binary64) */
-AIVC_HD double aivc_det_exp(double x) {
-  if (x != x) return x;
-  if (x > 709.0) return aivc_bits_to_f64(0x7FF0000000000000ull);
-  if (x < -745.0) return 0.0;
+/* exp(x) for finite -745 <= x <= 709: the arithmetic of aivc_det_exp without its range tests */
+AIVC_HD double aivc_det_exp_core(double x) {
   const double INV_LN2 = 1.4426950408889634074;
   const double LN2_HI = 6.93147180369123816490e-01; /* 0x3FE62E42FEE00000 */
   const double LN2_LO = 1.90821492927058770002e-10; /* 0x3DEA39EF35793C76 */
@@ -77,30 +74,38 @@ AIVC_HD double aivc_det_exp(double x) {
   const int k2 = k - k1;
   return (p * aivc_pow2i(k1)) * aivc_pow2i(k2);
 }
+/* exp(x), |rel err| < ~2 ulp(binary64) */
+AIVC_HD double aivc_det_exp(double x) {
+  if (x != x) return x;
+  if (x > 709.0) return aivc_bits_to_f64(0x7FF0000000000000ull);
+  if (x < -745.0) return 0.0;
+  return aivc_det_exp_core(x);
+}
 
+/* x * (1 + x/2 + x^2/6 + ...), degree 16 in total: expm1(x) for |x| < 0.34 */
+AIVC_HD double aivc_det_expm1_small(double x) {
+  double p = 1.0 / 20922789888000.0; /* 1/16! */
+  p = AIVC_FMA(p, x, 1.0 / 1307674368000.0);
+  p = AIVC_FMA(p, x, 1.0 / 87178291200.0);
+  p = AIVC_FMA(p, x, 1.0 / 6227020800.0);
+  p = AIVC_FMA(p, x, 1.0 / 479001600.0);
+  p = AIVC_FMA(p, x, 1.0 / 39916800.0);
+  p = AIVC_FMA(p, x, 1.0 / 3628800.0);
+  p = AIVC_FMA(p, x, 1.0 / 362880.0);
+  p = AIVC_FMA(p, x, 1.0 / 40320.0);
+  p = AIVC_FMA(p, x, 1.0 / 5040.0);
+  p = AIVC_FMA(p, x, 1.0 / 720.0);
+  p = AIVC_FMA(p, x, 1.0 / 120.0);
+  p = AIVC_FMA(p, x, 1.0 / 24.0);
+  p = AIVC_FMA(p, x, 1.0 / 6.0);
+  p = AIVC_FMA(p, x, 0.5);
+  p = AIVC_FMA(p, x, 1.0);
+  return p * x;
+}
 /* expm1(x) */
 AIVC_HD double aivc_det_expm1(double x) {
   if (x != x) return x;
-  if (AIVC_FABS(x) < 0.34) {
-    /* x * (1 + x/2 + x^2/6 + ...), degree 16 in total */
-    double p = 1.0 / 20922789888000.0; /* 1/16! */
-    p = AIVC_FMA(p, x, 1.0 / 1307674368000.0);
-    p = AIVC_FMA(p, x, 1.0 / 87178291200.0);
-    p = AIVC_FMA(p, x, 1.0 / 6227020800.0);
-    p = AIVC_FMA(p, x, 1.0 / 479001600.0);
-    p = AIVC_FMA(p, x, 1.0 / 39916800.0);
-    p = AIVC_FMA(p, x, 1.0 / 3628800.0);
-    p = AIVC_FMA(p, x, 1.0 / 362880.0);
-    p = AIVC_FMA(p, x, 1.0 / 40320.0);
-    p = AIVC_FMA(p, x, 1.0 / 5040.0);
-    p = AIVC_FMA(p, x, 1.0 / 720.0);
-    p = AIVC_FMA(p, x, 1.0 / 120.0);
-    p = AIVC_FMA(p, x, 1.0 / 24.0);
-    p = AIVC_FMA(p, x, 1.0 / 6.0);
-    p = AIVC_FMA(p, x, 0.5);
-    p = AIVC_FMA(p, x, 1.0);
-    return p * x;
-  }
+  if (AIVC_FABS(x) < 0.34) return aivc_det_expm1_small(x);
   if (x < -60.0) return -1.0;
   return aivc_det_exp(x) - 1.0;
 }
@@ -218,6 +223,26 @@ AIVC_HD uint16_t aivc_cdf_quant(float cdf, int k) {
 }
 AIVC_HD uint16_t aivc_laplace_cdf_u16(int k, float sigma) {
   return aivc_cdf_quant(aivc_laplace_cdf((float)k - 256.5f, sigma), k);
+}
+/* The scale of the Laplace law as aivc_laplace_cdf derives it from sigma (one IEEE division). */
+AIVC_HD float aivc_laplace_scale(float sigma) { return sigma / 1.41421354f; }
+/* aivc_laplace_cdf_u16(k, sigma) for b = aivc_laplace_scale(sigma), sigma > 0 and not NaN, 0 <= k <= 512: the same
+ * operations on the same values, laid out for a wavefront that evaluates one entry per lane in the range decoder's rare
+ * path (csrc/entropy.hip) -- the argument of expm1 is clamped to the saturation point instead of branching around the
+ * fp64 work (expm1f(x) = -1 for x < -17.5 either way), and exp() runs without its NaN / overflow / underflow tests
+ * (x is in [-17.5, -0.34] there).  Equality with aivc_laplace_cdf_u16 over sigma and k is a test
+ * (tests/test_oracle_golden.py::test_laplace_tail_entries_equal_row_entries). */
+AIVC_HD uint16_t aivc_laplace_cdf_u16_scale(int k, float b) {
+  const float t = (float)k - 256.5f; /* never 0 */
+  const float at = t < 0.0f ? -t : t;
+  const float a = at / b;
+  const float x = -a;
+  const float xc = x < -17.5f ? -17.5f : x;
+  const double xd = (double)xc;
+  const double em = AIVC_FABS(xd) < 0.34 ? aivc_det_expm1_small(xd) : aivc_det_exp_core(xd) - 1.0;
+  const float e = x < -17.5f ? -1.0f : (float)em;
+  const float hs = t < 0.0f ? -0.5f : 0.5f;
+  return aivc_cdf_quant(0.5f - hs * e, k);
 }
 
 #endif /* AIVC_DETMATH_H */

@@ -368,6 +368,19 @@ def laplace_cdf_rows(sigma, maps):
     return rows
 
 
+def laplace_tail_mismatches(sigma):
+    """entries 0..512 of every sigma: aivc_laplace_cdf_u16_scale (the range decoder's rare path) vs aivc_laplace_cdf_u16
+    -> (number of differing entries, (index, k) of the first)"""
+    sigma = _f32(sigma).reshape(-1)
+    lib()
+    fn = _lib.aivc_oracle_laplace_tail_mismatches
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    fi, fk = C.c_int64(-1), C.c_int32(-1)
+    bad = fn(_p(sigma), sigma.size, C.byref(fi), C.byref(fk))
+    return int(bad), (int(fi.value), int(fk.value))
+
+
 def laplace_cdf_windows(sigma, maps):
     """-> (win [n_pos][CDF_WIN] uint16, sigma_pos [n_pos] float32): the decoder's fast-path window of every row"""
     sigma = _f32(sigma)

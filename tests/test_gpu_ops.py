@@ -307,7 +307,7 @@ def test_range_encoder_batches_ragged_streams_and_long_straddle_runs(kernel, ora
         assert out_h[off:off + int(n)].tobytes() == w, (kernel, i, lens[i])
 
 
-@pytest.mark.parametrize('scale', [0.4, 3.0, 40.0])
+@pytest.mark.parametrize('scale', [0.4, 3.0, 40.0, 150.0])
 def test_range_decode_from_windows(scale, oracle, cuda):
     """64-entry CDF windows + sigma per position (what the codec's decoder reads) give the symbols of the full rows,
     in and outside the window; the windows equal the oracle's and the slice of the full rows"""
@@ -333,6 +333,28 @@ def test_range_decode_from_windows(scale, oracle, cuda):
     assert len(payload) == (int(bits.cpu()[0]) + 2 + 7) // 8
     if scale >= 40.0:
         assert (np.abs(q[..., maps]) > 32).any(), 'the slow path (symbol outside the window) must be exercised'
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('sigma', [0.7, 30.0, 148.0, 600.0])
+def test_range_decode_from_windows_of_a_foreign_stream(sigma, oracle, cuda):
+    """Bytes no encoder of these CDFs wrote (a corrupt or foreign stream): the decoder's rare path must end its search
+    whatever the stream asks for -- at large sigma entry 0 of a row is not 0 and the stream can ask for less -- and
+    return what the kernel that searches full rows returns (and the oracle, where every count has a symbol: once a
+    stream asks for less than entry 0 the interval is invalid and torchac's own arithmetic is undefined)."""
+    from aivc_amd import ops
+    rng = np.random.default_rng(int(sigma * 10))
+    n_sym = 3000
+    sig = np.full((1, 1, n_sym, 1), sigma, np.float32)
+    payload = bytes(rng.integers(0, 256, 6000, dtype=np.uint8)) if sigma != 30.0 else bytes(6000)
+    rows = oracle.laplace_cdf_rows(sig, [0])
+    want = oracle.range_decode(payload, rows, n_sym)
+    win, sp = ops.laplace_cdf_windows(T(sig, cuda), [0])
+    got_w = ops.range_decode([payload], win, [0], [n_sym], [0], sigma_pos=sp)[0]
+    got_r = ops.range_decode([payload], ops.laplace_cdf_rows(T(sig, cuda), [0]), [0], [n_sym], [0])[0]
+    assert torch.equal(got_w, got_r)
+    if int(rows[0, 0]) == 0:
+        eq(got_w, want)
 
 
 @pytest.mark.parametrize('sigma', [1e-4, 0.3, 5.0, 148.0])

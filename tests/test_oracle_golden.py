@@ -223,3 +223,17 @@ def test_container_bytes(golden):
     assert got == gops
     assert hdr.gop_header_bytes('2_GOP_16', 0.) == g['gop_header_2_GOP_16'].tobytes()
     assert hdr.parse_gop_header(g['gop_header_2_GOP_16'].tobytes()) == ('2_GOP_16', 0.0)
+
+
+def test_laplace_tail_entries_equal_row_entries(oracle):
+    """include/aivc_detmath.h: aivc_laplace_cdf_u16_scale (the layout of the row function the range decoder's rare path
+    evaluates, one entry per lane, without divergent branches) returns the row function's entry for every k and every
+    sigma tried: log-uniform over the positive floats, dense over the range the codec's sigmas live in, the saturation
+    and small-argument switch points, zero and infinity."""
+    rng = np.random.default_rng(5)
+    s = np.concatenate([np.exp(rng.uniform(np.log(1e-8), np.log(1e8), 20000)),
+                        np.exp(rng.uniform(np.log(0.01), np.log(400.0), 100000)),
+                        np.array([0.0, 1e-30, 1e-38, 1e-45, 3.4e38, np.inf, 0.11, 1.0, 30.0, 131.0, 131.5, 132.0, 148.4,
+                                  24.7487, 2.0 ** -10])]).astype(np.float32)
+    bad, first = oracle.laplace_tail_mismatches(s)
+    assert bad == 0, (bad, first, float(s[first[0]]))

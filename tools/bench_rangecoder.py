@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Tuning aid: per-symbol cost of range_encode_kernel / range_decode_kernel on Laplace-coded latents.
+"""Tuning aid: per-symbol cost of the range encoder and of both decoders (full CDF rows: the table-mode kernel; 64-entry
+windows + scale per position: what the codec's y streams use) on Laplace-coded latents.
 usage: bench_rangecoder.py   (env NSTREAMS, MAPS, SCALE)"""
 import os
 import sys
@@ -40,10 +41,14 @@ def main():
                 for i in range(nstreams):
                     ops.laplace_cdf_rows(sigma, maps, out=rows, row_off=i * nsym)
                 ms_d, dec = timed(lambda: ops.range_decode(payloads, rows, [i * nsym for i in range(nstreams)], [nsym] * nstreams, [0] * nstreams))
+                win, sp = ops.laplace_cdf_windows(sigma, maps)
+                ms_w, dec_w = timed(lambda: ops.range_decode(payloads, win, [0] * nstreams, [nsym] * nstreams, [0] * nstreams, sigma_pos=sp))
                 sym = (q[0].reshape(-1, c)[:, :n_maps].t().reshape(-1).to(torch.int32) + 256).to(torch.int16)
-                ok = all(torch.equal(d, sym) for d in dec)
-                print('streams %2d maps %2d sigma %5.1f: %6d sym/stream  %5.2f bit/sym  encode %6.2f ms (%.3f us/sym)  decode %6.2f ms (%.3f us/sym)  %s'
-                      % (nstreams, n_maps, sig, nsym, 8.0 * lens_h.mean() / nsym, ms_e, ms_e * 1e3 / nsym, ms_d, ms_d * 1e3 / nsym, 'ok' if ok else 'MISMATCH'))
+                ok = all(torch.equal(d, sym) for d in dec) and all(torch.equal(d, sym) for d in dec_w)
+                outside = float(((q[..., :n_maps] < -32) | (q[..., :n_maps] > 30)).float().mean())
+                print('streams %2d maps %2d sigma %5.1f: %6d sym/stream  %5.2f bit/sym  %4.1f %% outside the window  encode %6.2f ms (%.3f us/sym)  decode rows %6.2f ms (%.3f us/sym)  windows %6.2f ms (%.3f us/sym)  %s'
+                      % (nstreams, n_maps, sig, nsym, 8.0 * lens_h.mean() / nsym, 100 * outside, ms_e, ms_e * 1e3 / nsym, ms_d, ms_d * 1e3 / nsym,
+                         ms_w, ms_w * 1e3 / nsym, 'ok' if ok else 'MISMATCH'))
 
 
 if __name__ == '__main__':

@@ -18,7 +18,8 @@ from aivc_amd.models import arch  # noqa: E402
 def main():
     dev = torch.device('cuda:0')
     model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=dev)
-    synth.calibrate_operating_point(model, dev)
+    ay = os.environ.get('ACTIVE_Y')  # e.g. 64,64: the high-rate operating point
+    synth.calibrate_operating_point(model, dev, **({'active_y': tuple(int(v) for v in ay.split(','))} if ay else {}))
     fc = FrameCodec(model, max_batch=64)
     fr = bench.gpu_synthetic_unit(1920, 1080, 128, 0, dev, 666)
     fr = fr + [fr[-1]] * 4
@@ -33,7 +34,8 @@ def main():
         pr.enable()
         blobs, recs, dd = fc.encode_units(units, '1_GOP_32')
         t1 = time.time()
-        torch.cuda.synchronize()
+        if not os.environ.get('NO_SYNC'):  # (NO_SYNC=1: as the bench runs it, the decoder issued behind the encoder)
+            torch.cuda.synchronize()
         t2 = time.time()
         dec = fc.decode_units(blobs, dd, dev)
         t3 = time.time()
@@ -44,6 +46,7 @@ def main():
           % ((t1 - t0) * 1e3, (t2 - t0) * 1e3, (t3 - t2) * 1e3, (t4 - t2) * 1e3))
     st = pstats.Stats(pr)
     st.sort_stats('cumulative').print_stats(38)
+    st.sort_stats('tottime').print_stats(22)
 
 
 if __name__ == '__main__':
