@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_FP32, PREC_BF16X3 = 0, 1  # aivc_conv_params.precision
 
 AIVC_OK = 0
@@ -42,7 +42,8 @@ class ConvParams(C.Structure):
                 ('flags', C.c_int32),
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
                 ('gdn_beta', _f), ('gdn_gamma', _f),
-                ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('precision', C.c_int32)]
+                ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('precision', C.c_int32),
+                ('w_bf16x3', C.c_void_p)]
 
 
 MAX_IMAGES = 3
@@ -101,6 +102,7 @@ PROTOTYPES = {
     'aivc_sq_err': [_f, _f, _sz, _f, _f],
     'aivc_conv2d': [_P(ConvParams)],
     'aivc_gdn_reparam': [_f, _f, _i32, _fl, _fl, _fl, _f, _f],
+    'aivc_split_weights_bf16x3': [_f, _i32, _i32, C.c_void_p],
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],

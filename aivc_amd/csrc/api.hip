@@ -60,10 +60,10 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
-  // 1000 + the fp32 code with the bf16x3 tile (0 = 128x128, 2 = 256x64): the precision mode takes this launch
+  // 1000 + the fp32 code with the mode's tile: the precision mode takes this launch
   if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
       aivc::conv2d_mfma_supported(*p))
-    return 1000 + 100 + 10 * (p->mode == AIVC_MODE_TCONV ? 1 : 0) + (p->c_out == 64 ? 2 : 0) + (p->gdn ? 50 : 0);
+    return 1000 + 100 + 10 * (p->mode == AIVC_MODE_TCONV ? 1 : 0) + aivc::conv2d_bf16x3_tile(*p) + (p->gdn ? 50 : 0);
   if (p->tail_c_out) {
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_tail_supported(*p)) return AIVC_ERR_UNSUPPORTED;
     return aivc::conv2d_mfma_variant(*p);
@@ -72,6 +72,11 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin_variant(*p);
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
   return 0;
+}
+
+AIVC_EXPORT int aivc_split_weights_bf16x3(const float *w, int32_t c_out, int32_t k_total, void *out, aivc_stream_t stream) {
+  if (!w || !out || c_out <= 0 || k_total <= 0 || k_total % 32 || ((uintptr_t)out & 15u) || ((uintptr_t)w & 7u)) return AIVC_ERR_ARG;
+  return aivc::split_weights_bf16x3(w, c_out, k_total, out, aivc::to_stream(stream));
 }
 
 AIVC_EXPORT int aivc_conv_images(const aivc_image_src *src, int32_t n_img, const aivc_conv_params *p, aivc_stream_t stream) {

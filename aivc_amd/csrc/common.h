@@ -75,7 +75,9 @@ bool conv2d_mfma_supported(const aivc_conv_params &p);
 bool conv2d_mfma_tail_supported(const aivc_conv_params &p);
 int conv2d_mfma_variant(const aivc_conv_params &p);
 bool conv2d_bf16x3_supported(const aivc_conv_params &p);  // conv_bf16x3.hip: the precision mode (aivc_conv_params.precision = 1)
-int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s);  // 100 + 10*mode + tile id (+50 fused gdn); 190 fused 1x1 tail
+int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s);
+int split_weights_bf16x3(const float *w, int c_out, int k_total, void *out, hipStream_t s);
+int conv2d_bf16x3_tile(const aivc_conv_params &p);  // tile id of the mode's launch (aivc_conv2d_variant)  // 100 + 10*mode + tile id (+50 fused gdn); 190 fused 1x1 tail
 bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p);
 int conv_images(const aivc_image_src *src, int n_img, const aivc_conv_params &p, hipStream_t s);  // conv_images.hip
 bool conv2d_thin_supported(const aivc_conv_params &p);

@@ -66,12 +66,31 @@ __device__ __forceinline__ void glds16(const float *base, uint32_t voff, uint32_
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
+// bf16x3: x = h + m + l exactly, each term the bf16 nearest (ties to even) to what is left: 8 + 8 + 8 significant bits.
+// Two values at a time (v_cvt_pk_bf16_f32 packs a pair); used by the K loop and by aivc_split_weights_bf16x3.
+__device__ __forceinline__ void bf16x3_split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto pk = [](float u, float v) {
+    const bf16x2 t = __builtin_convertvector((f32x2){u, v}, bf16x2);  // round to nearest even
+    return __builtin_bit_cast(uint32_t, t);
+  };
+  h = pk(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
+  m = pk(r0, r1);
+  const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
+  l = pk(q0, q1);
+}
+
 // PREC: 0 = the fp32 arithmetic contract (v_mfma_f32_32x32x2_f32, fixed-order fmaf chains); 1 = "bf16x3" (round 5, a
 // precision MODE, never the default): every fp32 operand is split exactly into three bf16 terms x = h + m + l and a
 // product a * b is the six bf16 MFMA products h h', h m', m h', m m', h l', l h' with fp32 accumulation
 // (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate per instruction) -- the dropped terms are below 2^-24 |a b|.
 // Same LDS image, loader, epilogues and fused phases; only the K loop's fragment reads and MFMAs differ.  Results are
 // NOT the contract's bits (other summation tree): parity per mode is reported by tests/test_gpu_precision.py.
+// PREC 2 = PREC 1 with the weights split ahead of the launch (aivc_conv_params.w_bf16x3): the B side of a stage is three
+// bf16 planes of [BN rows][32 k] (64 bytes per row and plane), fetched by the same LDS-DMA, and a fragment is one
+// ds_read_b128 per term; the same terms in the same products as PREC 1, so the same bits.
 template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool TAIL = false, bool GLDS = false, int PREC = 0>
 __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1))))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -383,7 +402,9 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
     //               channels) quad: every lane decodes the quad of its chunk once per K-tile -- the same for all of its
     //               rows -- and clamps per row; the quads beyond K of the last tile write zeros instead of loading.
     static_assert(!GDN && (FASTK || MODE == AIVC_MODE_CONV), "LDS-DMA loop: conv / transposed conv (c_in % 32 == 0), conv (any c_in % 4 == 0)");
-    constexpr int ROWB = BK * 4, STAGE_B = (BM + BN) * ROWB, GA = BM / 32, GB = BN / 32;
+    // (PREC 2: B rows are 3 planes x 64 bytes; one DMA instruction covers 16 rows of one plane, 3 BN / 16 of them per stage)
+    constexpr int ROWB = BK * 4, BPLANE = BN * 64, STAGE_B = PREC == 2 ? BM * ROWB + 3 * BPLANE : (BM + BN) * ROWB;
+    constexpr int GA = BM / 32, GB = PREC == 2 ? 3 * BN / 64 : BN / 32;
     char *ring = reinterpret_cast<char *>(smem);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
     const int l3 = lane >> 3;
@@ -412,11 +433,21 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
     }
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-      const int co = n0 + 32 * j + 8 * wave + l3;
-      const int coc = co < Cout ? co : Cout - 1;  // rows beyond c_out are never stored
-      g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + (FASTK ? chunk_b : 0u);
+      if constexpr (PREC == 2) {
+        // instruction q of the stage's 3 BN / 16: plane q / (BN / 16), rows 16 (q % (BN / 16)) ..; lane -> row + (lane >> 2),
+        // LDS chunk slot lane & 3 holds data chunk slot ^ ((row >> 2) & 3): the 16 lanes of a ds_read_b128 phase then
+        // hit 16 different bank quads (rows of 64 bytes)
+        const int q = wave * GB + j, pl = q / (BN / 16), r = 16 * (q % (BN / 16)) + (lane >> 2);
+        const int co = n0 + r, coc = co < Cout ? co : Cout - 1;
+        g_bvo[j] = (uint32_t)coc * (uint32_t)(ks * ks * Cin * 6) + (uint32_t)(pl * 64) + (uint32_t)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+      } else {
+        const int co = n0 + 32 * j + 8 * wave + l3;
+        const int coc = co < Cout ? co : Cout - 1;  // rows beyond c_out are never stored
+        g_bvo[j] = (uint32_t)coc * (uint32_t)((TCONV ? ks * ks * Cin : K) * 4) + (FASTK ? chunk_b : 0u);
+      }
     }
     const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+    const uint32_t bwdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(BM * ROWB) + (uint32_t)wave * (uint32_t)(GB * 1024));  // PREC 2: this wave's B instructions
     // tiles are issued in K order: the (tap, channel offset) of the next one is kept as running scalars
     int ty = 0, tx = 0, ci0 = 0;
     const float *wrun = p.w;  // conv: weight row offset of the next tile
@@ -472,8 +503,17 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
           else *reinterpret_cast<float4 *>(ring + stage * STAGE_B + (32 * j + 8 * wave) * ROWB + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+      if constexpr (PREC == 2) {
+        // tile t of the split weights: 192 bytes per row and tile (aivc_split_weights_bf16x3)
+        const int kidx = TCONV ? ((ky0 + 2 * ty) * ks + kx0 + 2 * tx) * Cin + ci0 : (int)(wrun - p.w);
+        const float *bs = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.w_bf16x3) + (size_t)(kidx / BK) * 192);
+        const uint32_t bdst = bwdst + (uint32_t)stage * STAGE_B;
 #pragma unroll
-      for (int j = 0; j < GB; ++j) glds16(bb, g_bvo[j], dst + BM * ROWB + j * 4096);
+        for (int j = 0; j < GB; ++j) glds16(bs, g_bvo[j], bdst + j * 1024);
+      } else {
+#pragma unroll
+        for (int j = 0; j < GB; ++j) glds16(bb, g_bvo[j], dst + BM * ROWB + j * 4096);
+      }
       wrun += BK;
       ci0 += BK;
       if (ci0 == Cin) {
@@ -520,7 +560,7 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
         }
       }
     };
-    if constexpr (PREC == 1) {
+    if constexpr (PREC != 0) {
       // ---- bf16x3 K loop: a K tile of 32 is two slabs of 16; a fragment = 8 consecutive k of one row (two 16-byte
       // chunks), lanes 0-31 take k 0-7 of the slab, lanes 32-63 k 8-15 (the operand layout of the 32x32x16 MFMA).
       // Per slab a wave splits its TM + TN raw fragments (44 vector instructions each) and issues 6 x TM x TN MFMAs.
@@ -541,7 +581,13 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
           a_rs[sl][c] = ring + (wm * TM * 32 + (lane & 31)) * ROWB + off;
           b_rs[sl][c] = ring + BM * ROWB + (wn * TN * 32 + (lane & 31)) * ROWB + off;
         }
-      Raw ra[2][TM], rb[2][TN];
+      // PREC 2: the lane's fragment of plane 0 (8 consecutive k of its row: chunk 2 slab + (lane >> 5), swizzled as the loader wrote it)
+      const char *b_rp[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+        b_rp[sl] = ring + BM * ROWB + (wn * TN * 32 + (lane & 31)) * 64 + (((2 * sl + (lane >> 5)) ^ ((lane >> 2) & 3)) << 4);
+      Raw ra[2][TM], rb[2][PREC == 2 ? 1 : TN];
+      Tri tbr[2][PREC == 2 ? TN : 1];
       auto read_slab = [&](auto SET, auto STAGE, auto SLAB) {
         constexpr int set = decltype(SET)::value, stage = decltype(STAGE)::value, sl = decltype(SLAB)::value;
 #pragma unroll
@@ -551,30 +597,22 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          rb[set][j].lo = *reinterpret_cast<const float4 *>(b_rs[sl][0] + stage * STAGE_B + j * 32 * ROWB);
-          rb[set][j].hi = *reinterpret_cast<const float4 *>(b_rs[sl][1] + stage * STAGE_B + j * 32 * ROWB);
+          if constexpr (PREC == 2) {
+            tbr[set][j].h = *reinterpret_cast<const u32x4 *>(b_rp[sl] + stage * STAGE_B + j * 32 * 64);
+            tbr[set][j].m = *reinterpret_cast<const u32x4 *>(b_rp[sl] + stage * STAGE_B + BPLANE + j * 32 * 64);
+            tbr[set][j].l = *reinterpret_cast<const u32x4 *>(b_rp[sl] + stage * STAGE_B + 2 * BPLANE + j * 32 * 64);
+          } else {
+            rb[set][j].lo = *reinterpret_cast<const float4 *>(b_rs[sl][0] + stage * STAGE_B + j * 32 * ROWB);
+            rb[set][j].hi = *reinterpret_cast<const float4 *>(b_rs[sl][1] + stage * STAGE_B + j * 32 * ROWB);
+          }
         }
-      };
-      // x = h + m + l exactly (each term the bf16 nearest to what is left: 8 + 8 + 8 significant bits)
-      auto split2 = [](float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        auto pk = [](float u, float v) {
-          const bf16x2 t = __builtin_convertvector((f32x2){u, v}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
-          return __builtin_bit_cast(uint32_t, t);
-        };
-        h = pk(x0, x1);
-        const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
-        m = pk(r0, r1);
-        const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
-        l = pk(q0, q1);
       };
       auto split = [&](const Raw &r) {
         uint32_t h[4], m[4], l[4];
-        split2(r.lo.x, r.lo.y, h[0], m[0], l[0]);
-        split2(r.lo.z, r.lo.w, h[1], m[1], l[1]);
-        split2(r.hi.x, r.hi.y, h[2], m[2], l[2]);
-        split2(r.hi.z, r.hi.w, h[3], m[3], l[3]);
+        bf16x3_split2(r.lo.x, r.lo.y, h[0], m[0], l[0]);
+        bf16x3_split2(r.lo.z, r.lo.w, h[1], m[1], l[1]);
+        bf16x3_split2(r.hi.x, r.hi.y, h[2], m[2], l[2]);
+        bf16x3_split2(r.hi.z, r.hi.w, h[3], m[3], l[3]);
         return Tri{(u32x4){h[0], h[1], h[2], h[3]}, (u32x4){m[0], m[1], m[2], m[3]}, (u32x4){l[0], l[1], l[2], l[3]}};
       };
       auto mm = [&](floatx16 &c, const u32x4 &x, const u32x4 &y) {
@@ -586,7 +624,10 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
 #pragma unroll
         for (int i = 0; i < TM; ++i) ta[i] = split(ra[set][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) tb[j] = split(rb[set][j]);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (PREC == 2) tb[j] = tbr[set][j];
+          else tb[j] = split(rb[set][j]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1232,6 +1273,7 @@ static int launch_cfg2(const aivc_conv_params &p, hipStream_t s) {
   dim3 grid((unsigned)a.gx * (unsigned)a.gy * (MODE == AIVC_MODE_TCONV ? 4u : 1u), 1, 1);
   size_t lds = (size_t)(BM + (TAIL && TAIL_N > BN ? TAIL_N : BN)) * LDS_STRIDE * sizeof(float);
   if (GLDS && lds < (size_t)2 * (BM + BN) * BK * sizeof(float)) lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  if (PREC == 2 && lds < (size_t)2 * (BM * BK * 4 + BN * 192)) lds = (size_t)2 * (BM * BK * 4 + BN * 192);
   if (lds > 64 * 1024) {
     static LdsOptIn opt_in;  // per instantiation, per device
     if (!opt_in.raise(reinterpret_cast<const void *>(&conv_mfma_kernel<MODE, WM, WN, TM, TN, FUSE, FASTK, TAIL, GLDS, PREC>), lds))
@@ -1449,12 +1491,59 @@ bool conv2d_bf16x3_supported(const aivc_conv_params &p) {
   return (uint64_t)p.h_in * p.w_in * p.c_in * 4ull < 0xFFFFFFF0ull;  // one image inside the loader's 32-bit byte offsets
 }
 
+template <int MODE, int PREC>
+static int launch_bf16x3_prec(const aivc_conv_params &p, hipStream_t s) {
+  if (p.c_out == 64) return p.gdn ? launch_cfg2<MODE, 4, 1, 2, 2, true, true, false, true, PREC>(p, s)
+                                  : launch_cfg2<MODE, 4, 1, 2, 2, false, true, false, true, PREC>(p, s);
+  return p.gdn ? launch_cfg2<MODE, 2, 2, 2, 2, true, true, false, true, PREC>(p, s)
+               : launch_cfg2<MODE, 2, 2, 2, 2, false, true, false, true, PREC>(p, s);
+}
+// Tile of a launch of the mode (the ids of aivc_conv2d_variant: 0 = 128x128, 2 = 256x64, 5 = 64x128, 6 = 128x64).  Weights
+// split in the K loop: wave tile 64x64 (the split is 44 vector instructions per fragment: smaller wave tiles are bound
+// by it).  Weights split ahead (w_bf16x3): measured per layer class on the bench's shapes (tools/bf16x3_probe.py,
+// TFLOP/s fp32-equivalent, in-loop | 64x64 wave tile | 32x64 wave tile): conv to 128 channels 163-181 | 174-204 | 161-182,
+// conv to 64 160 | 162 | 173, transposed to 128 153 | 153 | 162, transposed to 64 149 | 139 | 151 (the 256x64 tile's ring
+// grows to 88 KB with the three weight planes: one workgroup per CU).
+int conv2d_bf16x3_tile(const aivc_conv_params &p) {
+  static const int force = getenv("AIVC_BF16X3_TILE") ? atoi(getenv("AIVC_BF16X3_TILE")) : 0;  // tuning aid: 1 = wave tile 64x64 everywhere
+  const bool ahead = p.w_bf16x3 != nullptr && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 6ull < 0xFFFFFFFFull;
+  if (!ahead || force == 1) return p.c_out == 64 ? 2 : 0;
+  if (p.c_out == 64) return 6;
+  return p.mode == AIVC_MODE_TCONV ? 5 : 0;
+}
+
 template <int MODE>
 static int launch_bf16x3(const aivc_conv_params &p, hipStream_t s) {
-  if (p.c_out == 64) return p.gdn ? launch_cfg2<MODE, 4, 1, 2, 2, true, true, false, true, 1>(p, s)
-                                  : launch_cfg2<MODE, 4, 1, 2, 2, false, true, false, true, 1>(p, s);
-  return p.gdn ? launch_cfg2<MODE, 2, 2, 2, 2, true, true, false, true, 1>(p, s)
-               : launch_cfg2<MODE, 2, 2, 2, 2, false, true, false, true, 1>(p, s);
+  // weights split ahead of the launch (aivc_split_weights_bf16x3) or by the K loop: the same terms, the same bits
+  const bool ahead = p.w_bf16x3 != nullptr && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 6ull < 0xFFFFFFFFull;
+  if (!ahead) return launch_bf16x3_prec<MODE, 1>(p, s);
+  switch (conv2d_bf16x3_tile(p)) {
+    case 6: return p.gdn ? launch_cfg2<MODE, 4, 1, 1, 2, true, true, false, true, 2>(p, s)
+                         : launch_cfg2<MODE, 4, 1, 1, 2, false, true, false, true, 2>(p, s);
+    case 5: return p.gdn ? launch_cfg2<MODE, 2, 2, 1, 2, true, true, false, true, 2>(p, s)
+                         : launch_cfg2<MODE, 2, 2, 1, 2, false, true, false, true, 2>(p, s);
+    default: return launch_bf16x3_prec<MODE, 2>(p, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, size_t pairs, int k_total, uint32_t *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pair (k, k + 1) of one row
+  if (i >= pairs) return;
+  const size_t half = (size_t)k_total / 2, co = i / half;
+  const int k = 2 * (int)(i - co * half);
+  const float2 x = *reinterpret_cast<const float2 *>(w + 2 * i);
+  uint32_t h, m, l;
+  bf16x3_split2(x.x, x.y, h, m, l);
+  uint32_t *dst = out + ((co * (size_t)(k_total / 32) + (size_t)(k / 32)) * 3) * 16 + (size_t)((k % 32) / 2);
+  dst[0] = h;
+  dst[16] = m;
+  dst[32] = l;
+}
+
+int split_weights_bf16x3(const float *w, int c_out, int k_total, void *out, hipStream_t s) {
+  const size_t pairs = (size_t)c_out * (size_t)k_total / 2;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, w, pairs, k_total, reinterpret_cast<uint32_t *>(out));
+  return check_launch("split_weights_bf16x3");
 }
 
 int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s) {

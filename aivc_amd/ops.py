@@ -115,6 +115,32 @@ def set_precision(mode):
     return prev
 
 
+_SPLIT_WEIGHTS = {}  # id(weight tensor) -> (weak reference, (data_ptr, version), its bf16x3 image); dies with the packed weight
+
+
+def split_weights_bf16x3(w_ohwi):
+    """aivc_split_weights_bf16x3 of an OHWI weight, once per tensor and version (aivc_conv_params.w_bf16x3).  The codec's
+    side streams launch convolutions too, so the (one-off) split is closed with a device-wide wait like every other
+    kernel-ready parameter (layers/_cache.py)."""
+    import weakref
+    key = id(w_ohwi)
+    stamp = (w_ohwi.data_ptr(), w_ohwi._version)
+    hit = _SPLIT_WEIGHTS.get(key)
+    if hit is not None and hit[0]() is w_ohwi and hit[1] == stamp:
+        return hit[2]
+    co = w_ohwi.shape[0]
+    k_total = w_ohwi.numel() // co
+    out = torch.empty(co * k_total * 6, dtype=torch.uint8, device=w_ohwi.device)
+    torch.cuda.synchronize(w_ohwi.device)
+    call('aivc_split_weights_bf16x3', _p(w_ohwi), co, k_total, _p(out), _stream())
+    torch.cuda.synchronize(w_ohwi.device)
+    _SPLIT_WEIGHTS[key] = (weakref.ref(w_ohwi, lambda _r, k=key: _SPLIT_WEIGHTS.pop(k, None)), stamp, out)
+    return out
+
+
+PRESPLIT_WEIGHTS = True  # bf16x3 mode: hand the kernels the split weights (False: they split in their K loop; same bits)
+
+
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
            res=None, algo=abi.ALGO_AUTO, gdn=None, tail=None):
     """x [n,h,w,c] -> y [n,ho,wo,co]; semantics of aivc_conv2d (include/aivc_hip.h).
@@ -172,6 +198,10 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
         p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, flags,
                            _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), None, None)
     p.precision = PRECISION
+    if PRECISION == abi.PREC_BF16X3 and PRESPLIT_WEIGHTS and w_ohwi.is_contiguous() and (w_ohwi.numel() // co) % 32 == 0:
+        from ._lib import load
+        if load()['aivc_conv2d_variant'](C.byref(p)) >= 1000:  # a launch the mode covers
+            p.w_bf16x3 = _p(split_weights_bf16x3(w_ohwi))
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
         return y

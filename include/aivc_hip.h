@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 12
+#define AIVC_ABI_VERSION 13
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -123,6 +123,10 @@ typedef struct aivc_conv_params {
                       * into three bf16 terms and a product is six bf16 MFMA products with fp32 accumulation -- within fp32
                       * summation-order noise of the contract's result but NOT its bits (tests/test_gpu_precision.py reports
                       * the error per layer class).  Never the default; bitstreams of the two modes do not interoperate. */
+  const void *w_bf16x3; /* ABI 13, optional, read under AIVC_PREC_BF16X3 only: the image of `w` that aivc_split_weights_bf16x3
+                         * wrote (c_out * ksize * ksize * c_in * 6 bytes).  Same results bit for bit as with NULL (the
+                         * kernels then split the weight fragments in their K loop, ~25 % slower): the terms are the same,
+                         * they are only computed once per layer instead of once per tile. */
 } aivc_conv_params;
 #define AIVC_PREC_FP32 0
 #define AIVC_PREC_BF16X3 1
@@ -137,9 +141,17 @@ typedef struct aivc_conv_params {
  * AIVC_ERR_UNSUPPORTED; callers then issue the two launches (aivc_conv2d_variant tells in advance). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
+/* AIVC_PREC_BF16X3, weights split ahead of the launches (aivc_conv_params.w_bf16x3): every weight of w [c_out][k_total]
+ * (k_total = ksize * ksize * c_in, a multiple of 32: the OHWI rows of aivc_conv2d) as its three bf16 terms
+ * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even; x = h + m + l exactly), laid out for the
+ * kernels' loader:  out[((co * k_total / 32 + t) * 3 + term) * 32 + k % 32]  as uint16, t = k / 32.
+ * out: c_out * k_total * 6 bytes, 16-byte aligned. */
+int aivc_split_weights_bf16x3(const float *w, int32_t c_out, int32_t k_total, void *out, aivc_stream_t stream);
+
 /* Which kernel aivc_conv2d would launch for these parameters (no launch): 0 = scalar kernel,
  * 1 = thin-output VALU kernel (transposed conv to 3 / 6 channels), otherwise 100 + 10 * template-mode (0 conv, 1 tconv, 2 gdn) + tile id (0: 128x128, 1: 64x64,
  * 2: 256x64, 3: 128x32, 4: 256x128, 5: 64x128, 6: 128x64) + 50 with a fused gdn; 190 = conv with a fused 1x1 tail (191: aivc_conv_images).
+ * 1000 + that code: the launch the precision mode takes (AIVC_PREC_BF16X3; the tile depends on whether w_bf16x3 is given).
  * Negative = error code.  Used by bench.py to attribute launch times and by callers to ask whether a fusion is available. */
 int aivc_conv2d_variant(const aivc_conv_params *p);
 

@@ -185,3 +185,52 @@ def test_codec_closed_loop_and_cross_mode_reconstruction(cuda):
     frac = sum(int((v > 0).sum()) for v in diff.values()) / sum(v.numel() for v in diff.values())
     print('\nsame latents, fp32 vs bf16x3 synthesis: %.4f %% of the 8-bit samples differ (by 1 LSB)' % (100 * frac))
     assert max(int(v.max()) for v in diff.values()) <= 1
+
+
+def test_weight_split_equals_the_oracle(cuda, oracle):
+    """aivc_split_weights_bf16x3: three bf16 terms per weight, x == h + m + l exactly, laid out [row][tile of 32][term][32]
+    -- HIP == the CPU restatement bit for bit, and the terms really sum to the weight"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((24, 3, 3, 32), dtype=np.float32) * np.exp(rng.uniform(-20, 20, (24, 1, 1, 1)))).astype(np.float32)
+    got = ops.split_weights_bf16x3(torch.from_numpy(w).to(cuda)).cpu().numpy().view(np.uint16)
+    want = np.empty(w.size * 3, np.uint16)
+    lib = oracle.lib()
+    assert lib['aivc_split_weights_bf16x3'](w.ctypes.data, 24, 288, want.ctypes.data, None) == 0
+    np.testing.assert_array_equal(got, want)
+    t = (got.reshape(24, 9, 3, 32).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    np.testing.assert_array_equal(t.sum(axis=2).reshape(24, 288), w.reshape(24, 288).astype(np.float64))
+
+
+@pytest.mark.parametrize('case', LAYERS + [(abi.MODE_CONV, 5, 2, 2, 64, 64, 40, 52, 1, False),
+                                          (abi.MODE_CONV, 3, 1, 1, 128, 256, 9, 70, 0, False),
+                                          (abi.MODE_TCONV, 5, 2, 0, 128, 64, 21, 37, 1, False)])
+def test_split_weights_ahead_of_the_launch_change_no_bit(case, cuda):
+    """aivc_conv_params.w_bf16x3: the kernels that read the weights' three terms from memory return exactly what the
+    kernels that split the fragments in their K loop return (partial tiles, both tile shapes, fused (I)GDN, residual)"""
+    from aivc_amd import ops
+    mode, k, s, pad, ci, co, h, w, gdn, use_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    x = torch.from_numpy(rng.standard_normal((3, h, w, ci), dtype=np.float32)).to(cuda)
+    wt = torch.from_numpy((rng.standard_normal((co, k, k, ci), dtype=np.float32) / np.sqrt(k * k * ci)).astype(np.float32)).to(cuda)
+    b = torch.from_numpy(rng.standard_normal(co, dtype=np.float32)).to(cuda)
+    g = None
+    if gdn:
+        g = (torch.from_numpy((np.abs(rng.standard_normal(co)) + 0.5).astype(np.float32)).to(cuda),
+             torch.from_numpy((np.abs(rng.standard_normal((co, co))) * 0.02).astype(np.float32)).to(cuda), gdn == 2)
+    ho, wo = abi.conv_out_size(mode, h, w, k, s, pad)
+    res = torch.from_numpy(rng.standard_normal((3, ho, wo, co), dtype=np.float32)).to(cuda) if use_res else None
+    prev = ops.set_precision('bf16x3')
+    try:
+        out = {}
+        for ahead in (False, True):
+            ops.PRESPLIT_WEIGHTS = ahead
+            out[ahead] = ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g, res=res)
+    finally:
+        ops.PRESPLIT_WEIGHTS = True
+        ops.set_precision(prev)
+    assert torch.equal(out[False], out[True])
+    ops.set_precision('fp32')
+    taps = (k * k + 3) // 4 if mode == abi.MODE_TCONV else k * k
+    if taps * ci >= 512:  # (shorter reductions stay on the fp32 kernels)
+        assert not torch.equal(ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g, res=res), out[True])  # (the mode did run)
