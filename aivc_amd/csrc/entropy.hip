@@ -1115,8 +1115,23 @@ AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *b
   const char *mode = getenv("AIVC_RC_ENCODE");  // (read per call: the tests run both kernels in one process)
   if (mode && !strcmp(mode, "wave"))
     hipLaunchKernelGGL(range_encode_kernel, dim3(batch->n_streams), dim3(64), 0, to_stream(stream), bounds, *batch, out, out_len);
-  else
-    hipLaunchKernelGGL(range_encode_lanes_kernel, dim3(1), dim3(192), 0, to_stream(stream), bounds, *batch, out, out_len);
+  else {
+    // A long launch asks for LDS it does not use, so that no convolution workgroup (16-100 KB of ring each) fits beside it
+    // on its CU: a coder wave that shares its SIMD with matrix-pipe waves runs 3.5-4x slower (every one of its dependent
+    // instructions waits for the issue port: tools/bench_rangecoder.py LOAD=1, 0.07 -> 0.29 us per symbol), and at high
+    // rate the last level's streams are the encoder's tail.  One CU of 256 for the duration of the launch; short launches
+    // (hidden under the transforms anyway) take what is free.
+    static const int own_cu = getenv("AIVC_RC_OWN_CU") ? atoi(getenv("AIVC_RC_OWN_CU")) : 1;  // tuning aid: 0 = never
+    uint32_t longest = 0;
+    for (int i = 0; i < batch->n_streams; ++i) longest = batch->s[i].n_sym > longest ? batch->s[i].n_sym : longest;
+    size_t pad_lds = 0;
+    if (own_cu && longest >= 65536u) {
+      static LdsOptIn opt_in;
+      pad_lds = 100 * 1024;  // + 48.5 KB of its own: 11 KB of the CU's 160 left
+      if (!opt_in.raise(reinterpret_cast<const void *>(range_encode_lanes_kernel), pad_lds)) pad_lds = 0;
+    }
+    hipLaunchKernelGGL(range_encode_lanes_kernel, dim3(1), dim3(192), pad_lds, to_stream(stream), bounds, *batch, out, out_len);
+  }
   return check_launch("range_encode");
 }
 
