@@ -236,8 +236,9 @@ def test_cdf_kernels_bit_exact(oracle, cuda):
 
 
 @pytest.mark.parametrize('n_sym,scale', [(1, 1.0), (63, 0.3), (64, 2.0), (65, 5.0), (1000, 0.05), (5000, 1.0),
-                                         (20000, 40.0), (3000, 1e-4)])
+                                         (20000, 40.0), (3000, 1e-4), (70000, 0.8)])
 def test_range_coder_bit_exact(n_sym, scale, oracle, cuda):
+    """(70000 symbols: the encoder launch that asks for a CU of its own, csrc/entropy.hip aivc_range_encode)"""
     from aivc_amd import ops
     rng = np.random.default_rng(n_sym)
     c = 4
