@@ -24,6 +24,9 @@ def main():
     g = None
     if os.environ.get('FUSE_GDN'):
         g = (torch.rand(co, device=dev) + 0.5, torch.rand(co, co, device=dev) * 0.01, False)
+    if os.environ.get('PRECISION'):  # e.g. bf16x3 (NO_PRESPLIT=1: the weights split in the K loop)
+        ops.set_precision(os.environ['PRECISION'])
+        ops.PRESPLIT_WEIGHTS = not os.environ.get('NO_PRESPLIT')
     for _ in range(reps):
         ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g)
     torch.cuda.synchronize()
