@@ -62,8 +62,8 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
   // 1000 + the fp32 code with the mode's tile: the precision mode takes this launch
   if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
-      aivc::conv2d_mfma_supported(*p))
-    return 1000 + 100 + 10 * (p->mode == AIVC_MODE_TCONV ? 1 : 0) + aivc::conv2d_bf16x3_tile(*p) + (p->gdn ? 50 : 0);
+      aivc::conv2d_mfma_supported(*p) && (!p->tail_c_out || aivc::conv2d_mfma_tail_supported(*p)))
+    return p->tail_c_out ? 1190 : 1000 + 100 + 10 * (p->mode == AIVC_MODE_TCONV ? 1 : 0) + aivc::conv2d_bf16x3_tile(*p) + (p->gdn ? 50 : 0);
   if (p->tail_c_out) {
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_tail_supported(*p)) return AIVC_ERR_UNSUPPORTED;
     return aivc::conv2d_mfma_variant(*p);
@@ -99,7 +99,7 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   hipStream_t s = aivc::to_stream(stream);
   // precision mode (never the default): the shapes it covers; everything else runs the fp32 contract
   if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
-      aivc::conv2d_mfma_supported(*p))
+      aivc::conv2d_mfma_supported(*p) && (!p->tail_c_out || aivc::conv2d_mfma_tail_supported(*p)))
     return aivc::conv2d_bf16x3(*p, s);
   if (p->gdn) {  // fused (I)GDN exists on the MFMA path only
     if (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p)) return AIVC_ERR_UNSUPPORTED;

@@ -95,7 +95,7 @@ template <int MODE, int WM, int WN, int TM, int TN, bool FUSE, bool FASTK, bool 
 __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN >= 8 ? 2 : (FUSE && TM * TN == 2 && WN == 2 && TM == 2 ? 3 : 1))))) void conv_mfma_kernel(MfmaArgs a) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(!TAIL || (MODE == AIVC_MODE_CONV && !FUSE && FASTK && BN == 64 && BN % BK == 0), "fused tail: conv, c_out 64");
-  static_assert(PREC == 0 || (GLDS && FASTK && !TAIL), "bf16x3: the LDS-DMA loop with c_in % 32 == 0");
+  static_assert(PREC == 0 || (GLDS && FASTK), "bf16x3: the LDS-DMA loop with c_in % 32 == 0");
   constexpr int UA = BM * OCT / 256;          // (row, octet) units per thread for A
   constexpr int UB = (BN * OCT + 255) / 256;  // ... for B
   constexpr bool B_FULL = (BN * OCT) % 256 == 0;  // every thread stages a B unit: no exec masking
@@ -1480,7 +1480,9 @@ int conv2d_mfma(const aivc_conv_params &p, hipStream_t s) {
 // instructions of operand splitting -- smaller wave tiles are bound by the splitting.
 bool conv2d_bf16x3_supported(const aivc_conv_params &p) {
   if (p.mode != AIVC_MODE_CONV && p.mode != AIVC_MODE_TCONV) return false;
-  if (p.tail_c_out || p.c_in % BK != 0) return false;
+  if (p.c_in % BK != 0) return false;
+  // fused 1x1 tail (its GEMM stays fp32, like the fused GDN's): the bottleneck blocks' 3x3 64 -> 64 + 1x1 64 -> 128
+  if (p.tail_c_out && (p.tail_c_out != TAIL_N || p.c_out != 64 || p.mode != AIVC_MODE_CONV || p.gdn || p.mul || !p.bias || !p.tail_bias)) return false;
   if (p.c_out != 64 && p.c_out % 128 != 0) return false;
   if (p.gdn && p.c_out != 64 && p.c_out != 128) return false;
   // short reductions (the 1x1 convs: two to four K tiles) are prologue / epilogue work on the mode's big tiles: they stay
@@ -1507,6 +1509,7 @@ static int launch_bf16x3_prec(const aivc_conv_params &p, hipStream_t s) {
 int conv2d_bf16x3_tile(const aivc_conv_params &p) {
   static const int force = getenv("AIVC_BF16X3_TILE") ? atoi(getenv("AIVC_BF16X3_TILE")) : 0;  // tuning aid: 1 = wave tile 64x64 everywhere
   const bool ahead = p.w_bf16x3 != nullptr && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 6ull < 0xFFFFFFFFull;
+  if (p.tail_c_out) return 6;  // fused tail: 128x64 either way (64 rows of 128 tail channels per wave would not fit the registers)
   if (!ahead || force == 1) return p.c_out == 64 ? 2 : 0;
   if (p.c_out == 64) return 6;
   return p.mode == AIVC_MODE_TCONV ? 5 : 0;
@@ -1516,6 +1519,10 @@ template <int MODE>
 static int launch_bf16x3(const aivc_conv_params &p, hipStream_t s) {
   // weights split ahead of the launch (aivc_split_weights_bf16x3) or by the K loop: the same terms, the same bits
   const bool ahead = p.w_bf16x3 != nullptr && (uint64_t)p.c_out * p.ksize * p.ksize * p.c_in * 6ull < 0xFFFFFFFFull;
+  if constexpr (MODE == AIVC_MODE_CONV) {
+    if (p.tail_c_out) return ahead ? launch_cfg2<MODE, 4, 1, 1, 2, false, true, true, true, 2>(p, s)
+                                   : launch_cfg2<MODE, 4, 1, 1, 2, false, true, true, true, 1>(p, s);
+  }
   if (!ahead) return launch_bf16x3_prec<MODE, 1>(p, s);
   switch (conv2d_bf16x3_tile(p)) {
     case 6: return p.gdn ? launch_cfg2<MODE, 4, 1, 1, 2, true, true, false, true, 2>(p, s)

@@ -237,8 +237,11 @@ def _conv2d_tail(x, w_ohwi, bias, stride, pad, act1, act2, res, algo, tail):
             raise AivcNativeError('conv2d: res shape %s != output shape %s' % (tuple(res.shape), tuple(y.shape)))
         p = abi.ConvParams(abi.MODE_CONV, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 0, 0,
                            _p(x), _p(w_ohwi), _p(bias), None, _p(res), _p(y), None, None, _p(w3), _p(b3), co2, 0)
+        p.precision = PRECISION
         variant = load()['aivc_conv2d_variant'](C.byref(p))
         fused = variant >= 0
+        if variant >= 1000 and PRESPLIT_WEIGHTS and w_ohwi.is_contiguous():
+            p.w_bf16x3 = _p(split_weights_bf16x3(w_ohwi))
     if not fused:  # two launches, same arithmetic
         t = conv2d(x, w_ohwi, bias, stride=stride, pad=pad, act1=act1, algo=algo)
         return conv2d(t, w3, b3, res=res, act2=act2, algo=algo)

@@ -119,7 +119,7 @@ typedef struct aivc_conv_params {
   int32_t tail_c_out;
   int32_t precision; /* AIVC_PREC_FP32 (0): the arithmetic contract above -- bit identical on every kernel and on the CPU
                       * oracle.  AIVC_PREC_BF16X3 (1, ABI 12): a precision MODE for CONV / TCONV with c_in % 32 == 0 and c_out
-                      * of 64 or a multiple of 128 (other shapes run the fp32 contract): every fp32 operand is split exactly
+                      * of 64 or a multiple of 128 (other shapes run the fp32 contract; a fused gdn / 1x1 tail keeps its fp32 GEMM): every fp32 operand is split exactly
                       * into three bf16 terms and a product is six bf16 MFMA products with fp32 accumulation -- within fp32
                       * summation-order noise of the contract's result but NOT its bits (tests/test_gpu_precision.py reports
                       * the error per layer class).  Never the default; bitstreams of the two modes do not interoperate. */

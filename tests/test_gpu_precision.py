@@ -234,3 +234,35 @@ def test_split_weights_ahead_of_the_launch_change_no_bit(case, cuda):
     taps = (k * k + 3) // 4 if mode == abi.MODE_TCONV else k * k
     if taps * ci >= 512:  # (shorter reductions stay on the fp32 kernels)
         assert not torch.equal(ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g, res=res), out[True])  # (the mode did run)
+
+
+def test_fused_tail_layer_in_the_mode(cuda):
+    """The bottleneck blocks' 3x3 64 -> 64 + fused 1x1 64 -> 128 (+ residual): the 3x3 runs in the mode, the 1x1 GEMM stays
+    fp32 -- within summation-order noise of the contract's result, weights split ahead or in the loop: the same bits"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(11)
+    n, h, w = 3, 37, 53
+    x = torch.from_numpy(rng.standard_normal((n, h, w, 64), dtype=np.float32)).to(cuda)
+    w1 = torch.from_numpy((rng.standard_normal((64, 3, 3, 64), dtype=np.float32) / 24.0).astype(np.float32)).to(cuda)
+    b1 = torch.from_numpy(rng.standard_normal(64, dtype=np.float32)).to(cuda)
+    w3 = torch.from_numpy((rng.standard_normal((128, 1, 1, 64), dtype=np.float32) / 8.0).astype(np.float32)).to(cuda)
+    b3 = torch.from_numpy(rng.standard_normal(128, dtype=np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, h, w, 128), dtype=np.float32)).to(cuda)
+
+    def run():
+        return ops.conv2d(x, w1, b1, stride=1, pad=1, act1=abi.ACT_RELU, res=res, tail=(w3, b3))
+    want = run()
+    prev = ops.set_precision('bf16x3')
+    try:
+        ops.PRESPLIT_WEIGHTS = False
+        in_loop = run()
+        ops.PRESPLIT_WEIGHTS = True
+        ahead = run()
+    finally:
+        ops.PRESPLIT_WEIGHTS = True
+        ops.set_precision(prev)
+    assert torch.equal(in_loop, ahead)
+    assert not torch.equal(ahead, want)  # (the mode did run)
+    d = (ahead.double() - want.double()).abs().max().item() / want.double().pow(2).mean().sqrt().item()
+    print('\nfused tail: bf16x3 vs fp32 contract, max |d| / rms = %.2e' % d)
+    assert d < 2e-5
