@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the measurements DESIGN.md section 7 quotes, all on one box
+# the measurements DESIGN.md section 7 quotes, all on one box (files named r05_*: rename per round)
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd $root
 mkdir -p gpurun_out
