@@ -621,7 +621,8 @@ def main():
             'fp32_contract_kernels_left': {'launches': sum(d[0] for d in fp.values()), 'ms_per_step': round(sum(d[2] for d in fp.values()) / args.precision_steps * 1e3, 2)},
             'note': 'precision MODE, not the headline: fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per '
                     'fp32 product, fp32 accumulation, for the conv / transposed conv layers with c_in % 32 == 0 and c_out of 64 / 128 '
-                    '(the image layers, the thin output layer, the fused 1x1 tail and the GDN GEMMs stay on the fp32 contract); '
+                    'and a reduction of 512 terms or more, weights split once per layer (the image layers, the thin output layer, the 1x1 convs '
+                    'and the second GEMMs of the fused GDN / 1x1 tail stay on the fp32 contract); '
                     'within fp32 summation-order noise of the contract, not its bits (tests/test_gpu_precision.py); encoder and '
                     'decoder must run the same mode'}
 
