@@ -52,9 +52,14 @@ def main():
     dev = torch.device('cuda:0')
     h, w, c = 68, 120, 64
     g = torch.Generator(device=dev).manual_seed(1)
-    for nstreams in (1, 8, 64):
-        for n_maps in (12, 64):
-            for sig in (0.3, 1.5, 6.0, 30.0):
+    only = os.environ.get('ONLY')  # e.g. 64,64,1.5: one configuration (counter passes)
+    cases = [(a, b, c_) for a in (1, 8, 64) for b in (12, 64) for c_ in (0.3, 1.5, 6.0, 30.0)]
+    if only:
+        a, b, c_ = only.split(',')
+        cases = [(int(a), int(b), float(c_))]
+    for nstreams, n_maps, sig in cases:
+        if True:
+            if True:
                 maps = list(range(n_maps))
                 sigma = (torch.rand((1, h, w, c), generator=g, device=dev) * 0.5 + 0.75) * sig
                 q = (torch.randn((1, h, w, c), generator=g, device=dev) * sigma * 0.7).round().clamp(-256, 255).to(torch.int16)
