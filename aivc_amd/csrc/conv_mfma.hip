@@ -1561,7 +1561,8 @@ int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s) {
   for (int n0 = 0; n0 < p.n; n0 += chunk) {
     aivc_conv_params q = p;
     q.n = p.n - n0 < chunk ? p.n - n0 : chunk;
-    const size_t in_off = (size_t)n0 * p.h_in * p.w_in * p.c_in, out_off = (size_t)n0 * p.h_out * p.w_out * p.c_out;
+    const size_t in_off = (size_t)n0 * p.h_in * p.w_in * p.c_in;
+    const size_t out_off = (size_t)n0 * p.h_out * p.w_out * (p.tail_c_out ? p.tail_c_out : p.c_out);  // (fused tail: y and res are the tail's)
     q.x = p.x + in_off;
     q.y = p.y + out_off;
     if (p.res) q.res = p.res + out_off;

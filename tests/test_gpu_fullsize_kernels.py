@@ -105,6 +105,13 @@ def test_batch_beyond_4gb_goes_out_as_sub_batches(cuda):
     for lo, hi in ((0, 17), (17, 34)):
         assert torch.equal(full[lo:hi], ops.conv2d(x[lo:hi].contiguous(), w, b, stride=2, pad=2, gdn=(beta, gamma, False)))
     del full
+    prev = ops.set_precision('bf16x3')  # the precision mode's launches split the same way (its own kernels)
+    try:
+        full = ops.conv2d(x, w, b, stride=2, pad=2, gdn=(beta, gamma, False))
+        assert torch.equal(full[30:34], ops.conv2d(x[30:34].contiguous(), w, b, stride=2, pad=2, gdn=(beta, gamma, False)))
+        del full
+    finally:
+        ops.set_precision(prev)
     wt = (torch.randn((32, 3, 3, 64), generator=g) / 24.0).to(cuda)
     bt = torch.randn(32, generator=g).to(cuda)
     full = ops.conv2d(x, wt, bt, mode=abi.MODE_TCONV, stride=2, act1=abi.ACT_LEAKY)
