@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 PREC_FP32, PREC_BF16X3 = 0, 1  # aivc_conv_params.precision
 
 AIVC_OK = 0
@@ -150,6 +150,10 @@ def declare(lib, suffix=''):
         var.argtypes = [_P(ConvParams)]
         var.restype = C.c_int
         fns['aivc_conv2d_variant'] = var
+        chk = lib.aivc_selfcheck_gdn_math  # diagnostic of the device arithmetic: no host twin
+        chk.argtypes = [C.c_uint64, C.c_uint32, _f, C.c_void_p]
+        chk.restype = C.c_int
+        fns['aivc_selfcheck_gdn_math'] = chk
     mws = getattr(lib, 'aivc_metrics_workspace' + suffix)
     mws.argtypes = [_i32, _i32, _i32]
     mws.restype = C.c_size_t

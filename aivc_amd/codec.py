@@ -68,13 +68,16 @@ class FrameCodec:
         # lazy: the first conv reads the sources itself (aivc_conv_images); packed only if a layer cannot
         return ops.ImageStack(parts, h, w, device)
 
-    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False, on_sections=None):
+    def encode_batch(self, cur, prev, nxt, frame_type, idx_rate=0., want_aux=False, on_sections=None, want_rec=True):
         """Encode n frames of the same type together.  cur/prev/nxt: lists of uint8 plane dicts
         (prev/nxt ignored where the frame type has no such reference).
         -> list of {'bytes', 'rec', 'data_dim'[, 'aux']}
         on_sections(sections): called once every latent of the batch is quantised -- BEFORE the CodecNet synthesis is
         queued -- so that the caller can send the non-zero-map flags on their way to the host (prepare_finalize)
-        half a batch earlier than the reconstructions exist."""
+        half a batch earlier than the reconstructions exist.
+        want_rec=False: the frames are no other frame's reference and the caller only wants their bitstream -- the
+        CodecNet synthesis (g_a_ref of the prediction, g_s, the 8-bit cast) is not run, 'rec' is [None] * n; the
+        sections are the same bytes either way (nothing the entropy coder reads depends on the reconstruction)."""
         n = len(cur)
         h, w = cur[0]['y'].shape[-2:]
         dev = cur[0]['y'].device
@@ -102,11 +105,14 @@ class FrameCodec:
             sections[i][2], sections[i][3] = sz, sy
         if on_sections is not None:
             on_sections(sections)
-        cod_out = self.cod.synthesise(c['y_hat'], pred)
-        _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
         data_dim = {'x': (h, w), 'y': c['dim_y'], 'z': c['dim_z'],
                     'x_uv': (math.ceil(h / 2), math.ceil(w / 2))}
-        recs = _unstack(dict(zip('yuv', rec8)), n)
+        if want_rec:
+            cod_out = self.cod.synthesise(c['y_hat'], pred)
+            _, rec8 = ops.frame_to_yuv420(cod_out, h, w, skip=skip, want_float=False)
+            recs = _unstack(dict(zip('yuv', rec8)), n)
+        else:
+            recs = [None] * n
         if want_aux:
             aux['code'] = ops.yuv420_to_444(cur_p['y'], cur_p['u'], cur_p['v'], c_store=3)
         return {'sections': sections, 'rec': recs, 'data_dim': data_dim, 'aux': aux}
@@ -343,9 +349,14 @@ class FrameCodec:
             for s in range(0, len(items), self.max_batch):
                 yield ftype, items[s:s + self.max_batch]
 
-    def encode_units(self, units, gop_name, idx_rate=0., shard=None):
+    def encode_units(self, units, gop_name, idx_rate=0., shard=None, recon='all'):
         """units: list of frame lists (display order, each len == len(GOP struct)).
         -> ([gop bytes per unit], [reconstructions per unit], data_dim)
+        recon: 'all' -- every frame is reconstructed, as the reference's encoder does (its forward pass returns x_hat
+        for every frame and the command line prints a PSNR from them); 'refs' -- a bitstream-only encoder: frames that
+        no other frame of the GOP structure references (the last dependency level of a random-access GOP: 16 of the 33
+        frames of 1_GOP_32; the last P of a low-delay chain) skip their CodecNet synthesis and come back as None.
+        Same bytes (tests/test_gpu_codec.py); single-process coding only.
         shard (aivc_amd.parallel.ClipShard, optional): the frames of every dependency level are spread over the
         ranks of this process' group; each rank codes `shard.mine(items)` and the new 8-bit reconstructions are
         exchanged once per level (they are the references of the next levels).  Stream scheduling is the
@@ -360,6 +371,11 @@ class FrameCodec:
         jobs = []
         waiting = None  # [(items, sections, flags on their way to the host) per batch] of the previous level
         split = shard is not None and shard.R > 1
+        if recon not in ('all', 'refs'):
+            raise ValueError("recon must be 'all' or 'refs'")
+        if recon == 'refs' and shard is not None:
+            raise ValueError("recon='refs' is a single-process option (the sharded paths exchange every reconstruction)")
+        referenced = {gop[f][k] for f in gop for k in ('prev_ref', 'next_ref') if gop[f].get(k) is not None}
 
         def flush(li):
             # the levels' coder launches are independent of each other: rotate the stream so that a level with
@@ -395,7 +411,8 @@ class FrameCodec:
                 out = self.encode_batch([units[u][frame_index(f)] for u, f in chunk],
                                         [rec[u].get(gop[f]['prev_ref']) for u, f in chunk],
                                         [rec[u].get(gop[f]['next_ref']) for u, f in chunk], ftype, idx_rate,
-                                        on_sections=lambda secs: preps.append(prepare_finalize(secs)))
+                                        on_sections=lambda secs: preps.append(prepare_finalize(secs)),
+                                        want_rec=recon == 'all' or any(f in referenced for _, f in chunk))
                 data_dim = out['data_dim']
                 for (u, f), r in zip(chunk, out['rec']):
                     rec[u][f] = r
@@ -549,7 +566,7 @@ class FrameCodec:
 
     # ------------------------------------------------------------------------------------------
     def encode_video(self, frames, gop_name, idx_starting_frame=0, idx_end_frame=None, idx_rate=0.,
-                     unit_filter=None):
+                     unit_filter=None, recon='all'):
         """frames[i] is the frame with absolute index idx_starting_frame + i.  The last intra-period
         unit is padded by repeating the last frame (src/model_mngt/model_management.py:142-153).
         unit_filter(u) -> bool selects the units this process codes (multi-GPU sharding); skipped
@@ -562,7 +579,7 @@ class FrameCodec:
         gops, recs, data_dim = [None] * nb_gop, [None] * nb_gop, None
         if mine:
             units = [[frames[min(u * unit + i, n - 1)] for i in range(unit)] for u in mine]
-            blobs, rr, data_dim = self.encode_units(units, gop_name, idx_rate)
+            blobs, rr, data_dim = self.encode_units(units, gop_name, idx_rate, recon=recon)
             for u, b, r in zip(mine, blobs, rr):
                 gops[u], recs[u] = b, r
         return {'gops': gops, 'recs': recs, 'data_dim': data_dim, 'nb_gop': nb_gop,

@@ -43,6 +43,59 @@ __device__ __forceinline__ float act_apply(int act, float v) {
   }
 }
 
+// ---- first-layer GDN epilogue (conv_images.hip): lean, correctly rounded sqrt / division ---------------------------------
+// __builtin_sqrtf / operator/ compile to the full IEEE sequences: operand scaling for denormals and extreme exponents
+// (v_div_scale, a compare + select + multiply in front of v_sqrt), the refinement, then unscaling and special-value
+// fix-up (v_div_fmas / v_div_fixup, v_cmp_class + select): 16 + 11 vector instructions (and three s_nop hazards) per
+// output, of which the refinement is 8 + 8.  The operands are ordinary numbers: a wavefront checks ONCE that all of its
+// normalisation sums s and numerators v lie in [2^-60, 2^60] (two instructions per output, gdn_range) and then runs only
+// the refinements below; any wavefront that fails the check takes the compiler's full sequences.  Inside that range no
+// scaling step of the full sequence fires and no fix-up applies, so:
+//   div_rn_safe   IS the hardware expansion of operator/ without its range handling (v_div_scale returns its operand,
+//                 v_div_fmas is a plain fma, v_div_fixup passes the quotient through): same bits by construction;
+//   sqrt_rn_safe  is the reciprocal-square-root refinement LLVM uses for an IEEE sqrt when fp32 denormals are flushed
+//                 (two coupled Newton steps and a final residual correction): correctly rounded, hence the same bits as
+//                 __builtin_sqrtf -- checked EXHAUSTIVELY over every float in the range by aivc_selfcheck_gdn_math
+//                 (tests/test_gpu_ops.py), which also compares div_rn_safe with operator/ on 2^34 random operand pairs.
+// Measured (round 5, experiments/r05.md 11): the image layer 3.67 -> 3.49 ms (1 image) / 5.47 -> 5.26 ms (2 images) per
+// 32 frames of 1080p; the same change in the fused-GDN epilogues of conv_mfma.hip measured NOTHING (+-1 % on every shape,
+// even without the range check): those kernels hide their epilogue behind the other workgroups' K loops.  Not applied there.
+constexpr float GDN_SAFE_LO = 0x1p-60f, GDN_SAFE_HI = 0x1p60f;
+__device__ __forceinline__ float sqrt_rn_safe(float s) {
+  const float y = __builtin_amdgcn_rsqf(s);
+  float g = s * y, h = 0.5f * y;
+  const float e = __builtin_fmaf(-h, g, 0.5f);
+  h = __builtin_fmaf(h, e, h);
+  g = __builtin_fmaf(g, e, g);
+  const float d = __builtin_fmaf(-g, g, s);
+  return __builtin_fmaf(d, h, g);
+}
+__device__ __forceinline__ float div_rn_safe(float v, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = v * r;
+  float t = __builtin_fmaf(-d, q, v);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-d, q, v);
+  return __builtin_fmaf(t, r, q);
+}
+// running maximum / minimum of |a| and s (v_max3_f32 / v_min3_f32: one instruction each for two values; a NaN operand is
+// ignored -- it propagates through either sequence alike)
+__device__ __forceinline__ void gdn_range(float &mx, float &mn, float a, float s) {
+  // (plain builtins: the backend fuses the pairs into v_max3_f32 / v_min3_f32; inline asm made it fence every
+  // instruction with an s_nop)
+  mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), s);
+  mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(a)), s);
+}
+__device__ __forceinline__ void gdn_range_pair(float &mx, float &mn, float s0, float s1) {  // two sums (signs matter)
+  mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0), s1);
+  mn = __builtin_fminf(__builtin_fminf(mn, s0), s1);
+}
+__device__ __forceinline__ bool gdn_range_ok(float mx, float mn) {  // wave-uniform: every lane's values are in range
+  return __builtin_amdgcn_ballot_w64(mn >= GDN_SAFE_LO && mx <= GDN_SAFE_HI) == __builtin_amdgcn_ballot_w64(true);
+}
+
 // Epilogue shared by every conv implementation (order fixed by include/aivc_hip.h).
 struct Epilogue {
   const float *bias, *mul, *res, *xin;  // xin: GDN input (same pixel/channel indexing as y)

@@ -279,6 +279,29 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
 
     // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes; the normalisation / activation
     // variant and the edge masking are chosen once per tile (uniform branch), not per element
+    // GDN: beta joins the normalisation sums here, and the wavefront learns whether all of its operands are ordinary
+    // numbers (common.h: the lean square root / division then replace the full IEEE sequences, same bits)
+    bool lean = false;
+    if (gdn) {
+      float mx = 0.0f, mn = GDN_SAFE_HI;
+      const bool inv = a.gdn == 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = acc2[j][r] + cbeta[j];
+      if (inv) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) gdn_range_pair(mx, mn, acc2[j][r], acc2[j][r + 1]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gdn_range(mx, mn, acc[j][r], acc2[j][r]);
+      }
+      lean = gdn_range_ok(mx, mn);
+    }
     const int oy = oy0 + wave;
     if (oy < a.ho) {
       // wave-uniform row base (scalar registers) + one 32-bit lane offset: the 32 store addresses of a lane are
@@ -289,9 +312,10 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       float *yrow = reinterpret_cast<float *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
       const uint32_t lane_off = (uint32_t)(4 * hh * IC_CO + p);
       const int cols = a.wo - ox0;  // output columns of this tile that exist (>= 1)
-      auto emit = [&](auto MODE, auto WHOLE) {
+      auto emit = [&](auto MODE, auto WHOLE, auto LEAN) {
         constexpr int MD = decltype(MODE)::value;  // 0 / 1 / 2: no GDN + none / leaky / relu, 3: GDN, 4: inverse GDN
         constexpr bool WH = decltype(WHOLE)::value;
+        constexpr bool LN = decltype(LEAN)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -300,8 +324,13 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
             const int m = mc + 4 * hh;
             float v = acc[j][r];
             if constexpr (MD >= 3) {
-              const float nrm = __builtin_sqrtf(acc2[j][r] + cbeta[j]);
-              v = MD == 4 ? v * nrm : v / nrm;
+              if constexpr (LN) {
+                const float nrm = sqrt_rn_safe(acc2[j][r]);
+                v = MD == 4 ? v * nrm : div_rn_safe(v, nrm);
+              } else {
+                const float nrm = __builtin_sqrtf(acc2[j][r]);
+                v = MD == 4 ? v * nrm : v / nrm;
+              }
             }
             if constexpr (MD == 1) v = v > 0.0f ? v : v * 0.01f;
             if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
@@ -314,13 +343,21 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       };
       using std::integral_constant;
       const int mode = gdn ? (a.gdn == 2 ? 4 : 3) : (a.act1 == AIVC_ACT_LEAKY ? 1 : (a.act1 == AIVC_ACT_RELU ? 2 : 0));
+      using no = integral_constant<bool, false>;
+      using yes = integral_constant<bool, true>;
       auto emit_m = [&](auto WHOLE) {
         switch (mode) {
-          case 0: emit(integral_constant<int, 0>{}, WHOLE); break;
-          case 1: emit(integral_constant<int, 1>{}, WHOLE); break;
-          case 2: emit(integral_constant<int, 2>{}, WHOLE); break;
-          case 3: emit(integral_constant<int, 3>{}, WHOLE); break;
-          default: emit(integral_constant<int, 4>{}, WHOLE); break;
+          case 0: emit(integral_constant<int, 0>{}, WHOLE, no{}); break;
+          case 1: emit(integral_constant<int, 1>{}, WHOLE, no{}); break;
+          case 2: emit(integral_constant<int, 2>{}, WHOLE, no{}); break;
+          case 3:
+            if (lean) emit(integral_constant<int, 3>{}, WHOLE, yes{});
+            else emit(integral_constant<int, 3>{}, WHOLE, no{});
+            break;
+          default:
+            if (lean) emit(integral_constant<int, 4>{}, WHOLE, yes{});
+            else emit(integral_constant<int, 4>{}, WHOLE, no{});
+            break;
         }
       };
       if (cols >= IC_TW) emit_m(integral_constant<bool, true>{});

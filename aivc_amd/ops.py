@@ -272,6 +272,14 @@ def gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
     return be, ge
 
 
+def selfcheck_gdn_math(n_div_pairs=1 << 34, seed=1, device=None):
+    """-> (sqrt mismatches over every float of the safe range, division mismatches over n_div_pairs random pairs):
+    the lean sequences of the fused GDN epilogues against the compiler's IEEE sqrt / division (aivc_selfcheck_gdn_math)"""
+    out = torch.zeros(2, dtype=torch.int64, device=device or torch.device('cuda'))
+    call('aivc_selfcheck_gdn_math', int(n_div_pairs), int(seed), _p(out), _stream())
+    return tuple(int(v) for v in out.cpu())
+
+
 def gdn(x, beta_eff, gamma_eff, inverse=False, res=None, algo=abi.ALGO_AUTO):
     c = x.shape[-1]
     mode = abi.MODE_IGDN if inverse else abi.MODE_GDN

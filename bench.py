@@ -253,6 +253,8 @@ def main():
     ap.add_argument('--entropy-lookahead', type=int, default=0, help='decoder: dependency levels of entropy decoding issued ahead (0: the whole clip up front)')
     ap.add_argument('--no-high-rate', action='store_true', help='skip the high-rate operating point (every y feature map coded) measured after the headline run')
     ap.add_argument('--high-rate-steps', type=int, default=3)
+    ap.add_argument('--no-lean-encoder', action='store_true', help="skip the bitstream-only encoder (recon='refs') measured after the headline run (its own object, never `value`)")
+    ap.add_argument('--lean-encoder-steps', type=int, default=2)
     ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
     ap.add_argument('--precision-steps', type=int, default=2)
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
@@ -575,6 +577,45 @@ def main():
                              'networks is coded: each frame carries two serial range-coder streams of h_y*w_y*%d symbols' % c_y}
         del model_hr, fc_hr
 
+    # ---- bitstream-only encoder (FrameCodec.encode_units(recon='refs'); never the headline: `value` keeps the encoder that
+    # reconstructs every frame, as the reference's does): frames no other frame references skip their CodecNet synthesis
+    lean_encoder = None
+    if rank == 0 and world == 1 and not args.no_lean_encoder:
+        with torch.no_grad():
+            ref_blobs, _, _ = fc.encode_units(clips[0], args.gop)
+            blobs, lean_recs, dd = fc.encode_units(clips[0], args.gop, recon='refs')
+            le_same = blobs == ref_blobs
+            le_skipped = sum(r is None for u in lean_recs for r in u)
+            dec = fc.decode_units(blobs, dd, dev)
+            le_closed = all(torch.equal(d[k], e[k]) for du, eu in zip(dec, lean_recs) for d, e in zip(du, eu) if e is not None for k in 'yuv')
+            le_errs = len(fc.stream_errors())
+            del dec, lean_recs, ref_blobs
+            torch.cuda.synchronize()
+            t0 = time.time()
+            evs = []
+            for i in range(args.lean_encoder_steps):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                blobs, _, dd = fc.encode_units(clips[(args.warmup + i) % len(clips)], args.gop, recon='refs')
+                ev[1].record()
+                fc.decode_units(blobs, dd, dev)
+                ev[2].record()
+                evs.append(ev)
+            torch.cuda.synchronize()
+            el_le = time.time() - t0
+        enc_le = sum(e[0].elapsed_time(e[1]) for e in evs) * 1e-3
+        dec_le = sum(e[1].elapsed_time(e[2]) for e in evs) * 1e-3
+        lean_encoder = {'value': round(args.lean_encoder_steps * args.frames / el_le, 4), 'unit': 'frames/s', 'steps': args.lean_encoder_steps,
+                        'ms_per_step': round(el_le / args.lean_encoder_steps * 1e3, 2),
+                        'encode_main_stream_fps': round(args.lean_encoder_steps * args.frames / enc_le, 3),
+                        'decode_main_stream_fps': round(args.lean_encoder_steps * args.frames / dec_le, 3),
+                        'frames_not_reconstructed_by_the_encoder': '%d of %d coded' % (le_skipped, coded),
+                        'bytes_equal_full_encoder': bool(le_same), 'closed_loop_ok_on_references': bool(le_closed), 'stream_errors': le_errs,
+                        'vs_headline': round(args.lean_encoder_steps * args.frames / el_le / (clips_done_for_hr / elapsed), 4),
+                        'note': "encode_units(recon='refs'): an encoder whose product is the bitstream -- the frames of the last dependency level "
+                                '(no other frame references them) skip the CodecNet synthesis the headline encoder runs for its PSNR print; '
+                                'same container bytes, the decoder is unchanged; reported beside the headline, never as `value`'}
+
     # ---- the bf16x3 precision MODE (aivc_conv_params.precision; never the headline: `value` stays the fp32 contract):
     # same clip, same model, same code path with the wide convolutions on six bf16 MFMA products per fp32 product
     precision_mode = None
@@ -666,7 +707,7 @@ def main():
             # bytes are unpinned here (no wheel in the image)
             'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate, 'precision_mode': precision_mode,
+            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
         }
         if other is not None:
             out['weak_scaling'] = other

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 13
+#define AIVC_ABI_VERSION 14
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -162,6 +162,13 @@ int aivc_conv2d_variant(const aivc_conv_params *p);
 int aivc_gdn_reparam(const float *beta, const float *gamma, int32_t c, float beta_bound,
                      float gamma_bound, float pedestal, float *beta_eff, float *gamma_eff,
                      aivc_stream_t stream);
+
+/* Diagnostic (no reference counterpart; nothing on the coded path calls it): the fused (inverse) GDN epilogues compute
+ * sqrt and division by the refinement steps of the IEEE sequences alone when a wavefront's operands all lie in
+ * [2^-60, 2^60] (aivc_amd/csrc/common.h).  This counts, on the device, the inputs for which those lean sequences differ
+ * from the compiler's full ones: mismatch[0] over EVERY float s in the range for the square root, mismatch[1] over
+ * n_div_pairs pseudo-random (numerator, denominator) pairs for the division.  Both must come back 0. */
+int aivc_selfcheck_gdn_math(uint64_t n_div_pairs, uint32_t seed, uint64_t *mismatch, aivc_stream_t stream);
 
 /* Zero-pad channels: in [npix][c_in] -> out [npix][c_out], c_out >= c_in, extra channels = 0. */
 int aivc_pad_channels(const float *in, size_t npix, int32_t c_in, float *out, int32_t c_out,

@@ -56,6 +56,38 @@ def test_batched_schedule_is_byte_identical(max_batch, cuda):
             assert torch.equal(d[k], e[k])
 
 
+@pytest.mark.parametrize('gop,n', [('1_GOP_8', 18), ('LDP_4', 10), ('1_GOP_0', 2)])
+def test_bitstream_only_encoder_same_bytes(gop, n, cuda):
+    """recon='refs': frames no other frame references skip their CodecNet synthesis -- same container bytes, the
+    references' reconstructions unchanged, the others None; the decoder reconstructs every frame from those bytes"""
+    from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    model, frames, dframes = _setup(cuda, 96, 64, n, seed=11)
+    fc = model.frame_codec()
+    g = generate_gop_struct(gop)
+    names = sorted(g, key=lambda f: int(f.split('_')[1]))
+    referenced = {g[f][k] for f in g for k in ('prev_ref', 'next_ref') if g[f][k] is not None}
+    with torch.no_grad():
+        full = fc.encode_video(dframes, gop)
+        lean = fc.encode_video(dframes, gop, recon='refs')
+        assert fc.assemble_video(lean) == fc.assemble_video(full)
+        dec, _, _, _ = fc.decode_video(fc.assemble_video(lean), cuda)
+    skipped = 0
+    for ru, rl in zip(full['recs'], lean['recs']):
+        for f, a, b in zip(names, ru, rl):
+            if f in referenced:
+                for k in 'yuv':
+                    assert torch.equal(a[k], b[k])
+            else:
+                assert b is None
+                skipped += 1
+    assert skipped == sum(f not in referenced for f in names) * len(full['recs']) > 0
+    for d, e in zip(dec, [r for u in full['recs'] for r in u]):
+        for k in 'yuv':
+            assert torch.equal(d[k], e[k])
+    with pytest.raises(ValueError):
+        fc.encode_video(dframes, gop, recon='none')
+
+
 def test_default_width_model_closed_loop(cuda):
     """full-width synthetic model at a small frame size: decoder == encoder reconstruction and the
     frame sections decode to the encoder's symbols (the reference's in-band self-check,

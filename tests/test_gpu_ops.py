@@ -479,6 +479,46 @@ def test_fused_gdn_bit_exact(case, oracle, cuda):
     eq(got, two)
 
 
+def test_gdn_lean_math_selfcheck(cuda):
+    """the lean square root / division of the fused GDN epilogues (csrc/common.h) == the compiler's IEEE sequences:
+    every float of the safe range for the square root, 2^34 random operand pairs for the division"""
+    from aivc_amd import ops
+    bad_sqrt, bad_div = ops.selfcheck_gdn_math(1 << 34, seed=20260929)
+    assert (bad_sqrt, bad_div) == (0, 0)
+
+
+@pytest.mark.parametrize('scale,zero_bias', [(1.0, False), (2.0 ** 70, False), (2.0 ** -70, True), (0.0, True), (2.0 ** 40, False)])
+@pytest.mark.parametrize('inv', [False, True])
+def test_fused_gdn_operand_range_fallback(scale, zero_bias, inv, oracle, cuda):
+    """operands far outside [2^-60, 2^60] (huge, tiny, exactly zero outputs) next to ordinary ones: the image layer
+    (5x5 s2 -> 64, aivc_conv_images) takes the full IEEE sequences for the wavefronts that see them and the lean ones
+    (csrc/common.h) for the others; the 3x3 128 -> 128 layer always the full ones: either way == oracle, bit for bit"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((2, 16, 32, 128), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    x[0, :8] *= np.float32(1.0 if scale >= 1 else 2.0 ** 60)  # mixed: some tiles in range, some not
+    wt = (rng.standard_normal((128, 3, 3, 128), dtype=np.float32) / 34.0).astype(np.float32)
+    bias = np.zeros(128, np.float32) if zero_bias else rng.standard_normal(128, dtype=np.float32)
+    beta = (np.abs(rng.standard_normal(128)) + 0.2).astype(np.float32)
+    gamma = (np.abs(rng.standard_normal((128, 128))) * 0.05).astype(np.float32)
+    with np.errstate(over='ignore', invalid='ignore'):
+        want = oracle.conv2d(x, wt, bias, stride=1, pad=1, gdn=(beta, gamma, inv))
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(bias, cuda), stride=1, pad=1, gdn=(T(beta, cuda), T(gamma, cuda), inv))
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # the first analysis layer from float sources (aivc_conv_images)
+    img = (rng.random((2, 16, 128, 4), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    img[..., 3] = 0
+    wi = np.zeros((64, 5, 5, 4), np.float32)
+    wi[..., :3] = rng.standard_normal((64, 5, 5, 3), dtype=np.float32) * 0.1
+    bi = np.zeros(64, np.float32) if zero_bias else rng.standard_normal(64, dtype=np.float32)
+    b64, g64 = beta[:64].copy(), gamma[:64, :64].copy()
+    with np.errstate(over='ignore', invalid='ignore'):
+        want_i = oracle.conv2d(img, wi, bi, stride=2, pad=2, gdn=(b64, g64, inv))
+    stack = ops.ImageStack([T(img, cuda)], 16, 128, cuda)
+    got_i = ops.conv2d(stack, T(wi, cuda), T(bi, cuda), stride=2, pad=2, gdn=(T(b64, cuda), T(g64, cuda), inv))
+    np.testing.assert_array_equal(got_i.cpu().numpy().view(np.uint32), want_i.view(np.uint32))
+
+
 @pytest.mark.parametrize('case', [
     # k, stride, cin, c_mid, c_tail, n, h, w, act1, act2, res
     (3, 1, 64, 64, 128, 2, 16, 32, abi.ACT_LEAKY, abi.ACT_LEAKY, True),   # whole 128-pixel tiles (the bottleneck block)

@@ -32,7 +32,7 @@ def test_hip_library_exports_every_declared_symbol():
     from aivc_amd import abi
     assert lib.aivc_abi_version() == abi.ABI_VERSION
     # every prototype bound by abi.py is declared in the header and vice versa
-    assert set(abi.PROTOTYPES) | {'aivc_abi_version', 'aivc_last_error', 'aivc_conv2d_variant'} == set(names)
+    assert set(abi.PROTOTYPES) | {'aivc_abi_version', 'aivc_last_error', 'aivc_conv2d_variant', 'aivc_selfcheck_gdn_math'} == set(names)
 
 
 def test_oracle_exports_ref_twins(oracle):

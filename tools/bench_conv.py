@@ -81,7 +81,11 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
-            print('%-32s algo=%d %s %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s' % (name, algo, '+gdn' if g is not None else '    ', ms, fl / 1e9, fl / ms / 1e9)
+            ops.PROFILE = []  # one more launch, to learn which kernel instantiation it was (aivc_conv2d_variant)
+            ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, algo=algo, gdn=g)
+            variant = ops.PROFILE[-1][0] if ops.PROFILE else -1
+            ops.PROFILE = None
+            print('%-32s algo=%d %s %8.3f ms  %7.1f GFLOP  %6.1f TFLOP/s  v%d' % (name, algo, '+gdn' if g is not None else '    ', ms, fl / 1e9, fl / ms / 1e9, variant)
                   + ('  clk %.3f GHz' % clk[1]() if clk else ''))
         tot_f += flops
         tot_t += ms
