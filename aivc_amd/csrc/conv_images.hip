@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       const uint64_t yb64 = (uint64_t)(uintptr_t)(a.y + (((size_t)b * a.ho + oy) * a.wo + ox0) * IC_CO);
       const uint32_t yb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(yb64 >> 32));  // (the builtin returns int:
       const uint32_t yb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)yb64);          //  no sign extension)
-      float *yrow = reinterpret_cast<float *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
+      // (a pointer rebuilt from integers has no address space: name it, or every store is a flat_store behind a 64-bit add)
+      typedef __attribute__((address_space(1))) float gfloat;
+      gfloat *yrow = reinterpret_cast<gfloat *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
       const uint32_t lane_off = (uint32_t)(4 * hh * IC_CO + p);
       const int cols = a.wo - ox0;  // output columns of this tile that exist (>= 1)
       auto emit = [&](auto MODE, auto WHOLE, auto LEAN) {
@@ -336,8 +338,10 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
             if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
             if (WH || m < cols) yrow[lane_off + (uint32_t)(mc * IC_CO + 32 * j)] = v;
             // keep the elements apart: interleaved sqrt / division sequences of many of them cost registers (the
-            // gamma fragments already take 64); a barrier every 2 / 4 / 16 elements measured the same
-            __builtin_amdgcn_sched_barrier(0);
+            // gamma fragments already take 64); a barrier every 2 / 4 / 16 elements measured the same with the full
+            // sequences.  The lean ones go in pairs: the second element's instructions fill the wait state behind
+            // v_rsq / v_rcp (an s_nop otherwise)
+            if (!LN || (r & 1)) __builtin_amdgcn_sched_barrier(0);
           }
         }
       };
