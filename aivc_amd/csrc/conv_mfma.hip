@@ -837,15 +837,34 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
     const bool whole = m0 + BM <= M;
     const bool has_res = p.res != nullptr;
     float rv[TM][16][TN2];
+    // residual and output addresses: ONE wave-uniform base per tile (scalar registers) + a 32-bit element offset per lane,
+    // rows and channel blocks as constants off it -- as 64-bit per-element pointers every access cost four vector
+    // instructions and two hazard nops of address arithmetic (this kernel runs two waves per SIMD: nothing hides them)
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) const float cgfloat;
+    const uint32_t lane_b = (uint32_t)(wrow * TAIL_N + col) * 4u;  // byte offset of this lane's first element in the tile
+    // rows k = 8 g + q (g = 0 .. 4 TM - 1, q = 0 .. 3) of the lane: one 32-bit offset per group g (4 KB apart), row and
+    // channel block inside the instruction's 12-bit immediate
+    auto group_off = [&](int g) {
+      uint32_t vo = lane_b + (uint32_t)(g * 8 * TAIL_N * 4);
+      asm volatile("" : "+v"(vo));  // (kept as a register: folded back into 64-bit address arithmetic otherwise)
+      return vo;
+    };
     auto fetch_res = [&](int i) {
       if (!has_res) return;
-      const float *rbase = p.res + (size_t)m0 * TAIL_N + col;
+      const gchar *rbase = (const gchar *)(uintptr_t)(p.res + (size_t)m0 * TAIL_N);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = i * 32 + (r & 3) + 8 * (r >> 2);
-        const int row = (whole || k < rows_left) ? wrow + k : 0;  // rows beyond M: any valid address, never stored
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint32_t vo = group_off(i * 4 + rq);
 #pragma unroll
-        for (int j = 0; j < TN2; ++j) rv[i][r][j] = rbase[(size_t)row * TAIL_N + 32 * j];
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rq * 4 + rr, k = i * 32 + rr + 8 * rq;
+          // rows beyond M: any valid address, never stored
+          const uint32_t off = (whole || k < rows_left) ? vo + (uint32_t)(rr * TAIL_N * 4) : (uint32_t)col * 4u;
+#pragma unroll
+          for (int j = 0; j < TN2; ++j) rv[i][r][j] = *reinterpret_cast<cgfloat *>(rbase + off + (uint32_t)(128 * j));
+        }
       }
     };
     {
@@ -928,25 +947,29 @@ __global__ __launch_bounds__(256, (PREC ? 1 : (TAIL ? AIVC_TAIL_WAVES : (TM * TN
       float cb[TN2];
 #pragma unroll
       for (int j = 0; j < TN2; ++j) cb[j] = p.tail_bias[col + 32 * j];
-      const uint32_t lane_off = (uint32_t)(lrow * TAIL_N + col) * 4u;
-      char *yb = reinterpret_cast<char *>(p.y + (size_t)(m0 + wm * TM * 32) * TAIL_N);
+      gchar *yb = (gchar *)(uintptr_t)(p.y + (size_t)m0 * TAIL_N);
       auto emit = [&](auto KIND, auto WHOLE) {
         constexpr int KD = decltype(KIND)::value;  // 0-2: act2 none/relu/leaky, no residual; 3-5: same after the residual
         constexpr bool WH = decltype(WHOLE)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int k = i * 32 + (r & 3) + 8 * (r >> 2);
-            if (!WH && k >= rows_left) continue;
-            char *yrow = yb + (size_t)k * (TAIL_N * 4);
+          for (int rq = 0; rq < 4; ++rq) {
+            const uint32_t vo = group_off(i * 4 + rq);
 #pragma unroll
-            for (int j = 0; j < TN2; ++j) {
-              float v = acc3[i][j][r] + cb[j];
-              if constexpr (KD >= 3) v = v + rv[i][r][j];
-              if constexpr (KD % 3 == 1) v = v > 0.0f ? v : 0.0f;
-              if constexpr (KD % 3 == 2) v = v > 0.0f ? v : v * 0.01f;
-              *reinterpret_cast<float *>(yrow + lane_off + 128 * j) = v;
+            for (int rr = 0; rr < 4; ++rr) {
+              const int r = rq * 4 + rr, k = i * 32 + rr + 8 * rq;
+              if (!WH && k >= rows_left) continue;
+#pragma unroll
+              for (int j = 0; j < TN2; ++j) {
+                float v = acc3[i][j][r] + cb[j];
+                if constexpr (KD >= 3) v = v + rv[i][r][j];
+                if constexpr (KD % 3 == 1) v = v > 0.0f ? v : 0.0f;
+                // leaky as a maximum: the same bits as the select for every input (v and 0.01 v have one sign, so no
+                // +0 / -0 question arises), one instruction and no condition-register hazard
+                if constexpr (KD % 3 == 2) v = __builtin_fmaxf(v, v * 0.01f);
+                *reinterpret_cast<gfloat *>(yb + vo + (uint32_t)(rr * TAIL_N * 4 + 128 * j)) = v;
+              }
             }
           }
       };
