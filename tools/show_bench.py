@@ -17,3 +17,8 @@ for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
             print('   %-34s %s' % (k, v))
     if d.get('cpu_baseline'):
         print('cpu_baseline', d['cpu_baseline'])
+    for key in ('high_rate', 'bitstream_only_encoder', 'precision_mode'):
+        o = d.get(key)
+        if o:
+            print(key, {k: o[k] for k in ('value', 'ms_per_step', 'vs_headline', 'encode_main_stream_fps', 'decode_main_stream_fps',
+                                           'bytes_equal_full_encoder', 'closed_loop_ok', 'closed_loop_ok_on_references') if k in o})
