@@ -35,7 +35,7 @@ for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True
             res.setdefault(short, {})[c] = sum(v) / len(v)  # mean over dispatches
 for k, d in res.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d:
-        d['mfma_busy_frac'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024.0)  # 256 CUs x 4 SIMDs
+        d['mfma_busy_frac'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024.0 / 8.0)  # 1024 SIMDs; GRBM_GUI_ACTIVE arrives summed over the 8 XCDs
 json.dump(res, open(out + '.json', 'w'), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
