@@ -16,8 +16,13 @@
 //     barrier inside; the zero fourth channel of every image is never multiplied (an exact no-op);
 //   - reduction order = the contract of the conv family (include/aivc_hip.h): kk = tap * c_in + 4 * image + c in
 //     groups of 8, inside a group in AIVC_K_ORDER -- octet o is quads 2 o (lanes 0-31) and 2 o + 1 (lanes 32-63);
-//   - fused GDN as in conv_mfma.hip (second MFMA GEMM over the squares); the squares of a wavefront's 32 pixels
-//     go through LDS rows only that wavefront touches, gamma comes from registers: no barrier, no shared staging.
+//   - the matrix product is taken TRANSPOSED (weights as the A operand, pixels as B: D[channel][pixel], the same fmaf
+//     chain per output -- the two factors of a product commute): accumulator register 4 o + s of lane half h then holds
+//     channel 8 o + s + 4 h of the lane's pixel, which is exactly the B operand the contract's K order asks of the
+//     second GEMM at step (o, s);
+//   - fused GDN as in conv_mfma.hip (second MFMA GEMM over the squares), but the squares go from the accumulators to
+//     the matrix pipe in registers (no LDS round trip, no barrier) and gamma is the A operand, resident in registers;
+//   - a lane owns 4 consecutive channels of its pixel per accumulator quad: outputs leave as 16-byte stores.
 // roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic FLOPs 2 * 25 * 3 n_img * 64 (+ 2 * 64 * 64 GDN) per output pixel.
 // Measured (r02, 16 x 1080p): 2.1 / 2.8 / 5.2 ms for 1 / 2 / 3 images against 1.9 / 2.8 / 3.7 ms of the generic kernel
 // on the packed tensor plus 0.2 / 0.4 / 0.6 ms to pack it: at par for one and two images (and 0.5 / 1 GB less HBM
@@ -46,17 +51,13 @@ constexpr int IC_PC = 2 * IC_TW + 3;    // patch columns
 constexpr int IC_HALF = IC_TW + 2;      // columns of one parity
 constexpr int IC_PLANE = IC_HALF * 4;   // floats of one (row, parity, image) plane
 constexpr int IC_CO = 64;
-constexpr int IC_LS = 36;               // LDS row stride of the GDN tiles (32 + 4)
 
 // weight row stride in floats: = 36 / 12 / 44 (mod 64), so the 16 lanes of a ds_read_b128 phase hit 16 distinct
 // bank quads
 template <int NIMG>
 constexpr int ic_wstride() { return NIMG == 2 ? 204 : 100 * NIMG; }
 template <int NIMG>
-constexpr int ic_region_floats() {  // patch, later the squares of the GDN (128 rows x 36)
-  const int patch = IC_PR * 2 * NIMG * IC_PLANE, gdn = 128 * IC_LS;
-  return patch > gdn ? patch : gdn;
-}
+constexpr int ic_region_floats() { return IC_PR * 2 * NIMG * IC_PLANE; }  // the patch
 template <int NIMG>
 constexpr int ic_lds_floats() { return IC_CO * ic_wstride<NIMG>() + ic_region_floats<NIMG>(); }
 
@@ -70,11 +71,16 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
   constexpr int K = 100 * NIMG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float lut[256];
+  __shared__ __attribute__((aligned(16))) float chan[2][IC_CO];  // bias, beta (a lane needs them by channel quad: broadcast reads)
   float *Wl = smem;
   float *patch = smem + IC_CO * WS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 31, hh = lane >> 5;
   lut[tid] = (float)tid / 255.0f;
+  if (tid < IC_CO) {
+    chan[0][tid] = a.bias ? a.bias[tid] : 0.0f;
+    chan[1][tid] = a.gdn ? a.gdn_beta[tid] : 0.0f;
+  }
   const int H = a.h, W = a.w_in, hc = (H + 1) / 2, wc = (W + 1) / 2;
   const uint32_t ntiles = (uint32_t)a.n * (uint32_t)a.tiles_y * (uint32_t)a.tiles_x;
   const uint32_t t_first = blockIdx.x * (uint32_t)IC_TPW;
@@ -101,14 +107,11 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
     }
   }
   const bool gdn = a.gdn != 0;
-  // B fragments of the GDN GEMM (gamma[i][k], i = 32 j + p, k = 32 c + 8 o + 4 hh ..): 16 float4 per lane, kept
+  // A fragments of the GDN GEMM (gamma[i][k], i = 32 j + p, k = 32 c + 8 o + 4 hh ..): 16 float4 per lane, kept
   // for all tiles -- the second GEMM then needs no shared staging, no barrier and no global latency per tile
   float4 greg[2][4][2];
-  float cbias[2], cbeta[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    cbias[j] = a.bias ? a.bias[32 * j + p] : 0.0f;
-    cbeta[j] = gdn ? a.gdn_beta[32 * j + p] : 0.0f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -171,13 +174,12 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
 
   const float *abase = patch + (2 * wave * 2 * NIMG * IC_HALF + p) * 4;
   const float *bbase = Wl + p * WS;
-  float *As = patch;  // the squares of the GDN reuse the patch: rows of wave w are written and read by wave w only
-  const float *a_frag = As + (wave * 32 + p) * IC_LS + hh * 4;
+  const float *cquad = &chan[0][0] + 4 * hh;  // this lane half's channel quads: channel 32 j + 8 q + 4 hh + s <-> register 4 q + s
 
   for (uint32_t t = t_first; t < t_end; ++t) {
     int b, oy0, ox0;
     tile_of(t, b, oy0, ox0);
-    __syncthreads();  // lut / weights (first tile); everybody is done with the previous tile's squares
+    __syncthreads();  // lut / weights / bias / beta (first tile); everybody is done reading the previous tile's patch
     {
       int tt = tid;
       asm volatile("" : "+v"(tt));
@@ -225,12 +227,13 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
         bf0 = af;
         bf1 = af;
       }
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf1.z, acc[1], 0, 0, 0);
+      // (weights are the A operand: D[channel][pixel])
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf0.x, af.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf1.x, af.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf0.y, af.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf1.y, af.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf0.z, af.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf1.z, af.z, acc[1], 0, 0, 0);
       // .w: the zero fourth channel of the image -- fmaf(0, w, acc) = acc, not issued
     }
 
@@ -239,7 +242,13 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] + cbias[j];
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4 *>(cquad + 32 * j + 8 * q);
+          acc[j][4 * q + 0] = acc[j][4 * q + 0] + b4.x;
+          acc[j][4 * q + 1] = acc[j][4 * q + 1] + b4.y;
+          acc[j][4 * q + 2] = acc[j][4 * q + 2] + b4.z;
+          acc[j][4 * q + 3] = acc[j][4 * q + 3] + b4.w;
+        }
     }
     floatx16 acc2[2];
     if (gdn) {
@@ -247,38 +256,27 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
-      __syncthreads();  // every wavefront is done reading the patch
+      // s[i][pixel] = sum over k = 32 c + 8 o + (s | 4 + s) of gamma[i][k] * x[k][pixel]^2, K order of the contract: the B
+      // operand of step (c, o, s) is the square of accumulator register 4 o + s of block c, as it stands
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          float xv = acc[c][r];
-          asm volatile("" : "+v"(xv));
-          As[(wave * 32 + m) * IC_LS + p] = xv * xv;
-        }
-        // rows of this wavefront only: the LDS executes a wavefront's accesses in order, no barrier needed
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
         for (int o = 0; o < 4; ++o) {
-          const float4 af = *reinterpret_cast<const float4 *>(a_frag + 8 * o);
           const float4 g0 = greg[c][o][0], g1 = greg[c][o][1];
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, g0.x, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, g1.x, acc2[1], 0, 0, 0);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, g0.y, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, g1.y, acc2[1], 0, 0, 0);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, g0.z, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, g1.z, acc2[1], 0, 0, 0);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, g0.w, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, g1.w, acc2[1], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            float xv = acc[c][4 * o + st];
+            asm volatile("" : "+v"(xv));  // keeps the squares inside the loop (hoisted, they cost 32 registers)
+            const float sq = xv * xv;
+            const float ga = st == 0 ? g0.x : (st == 1 ? g0.y : (st == 2 ? g0.z : g0.w));
+            const float gb = st == 0 ? g1.x : (st == 1 ? g1.y : (st == 2 ? g1.z : g1.w));
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, sq, acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gb, sq, acc2[1], 0, 0, 0);
+          }
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
 
-    // ---- epilogue: lanes 0-31 of an accumulator row write 128 contiguous bytes; the normalisation / activation
-    // variant and the edge masking are chosen once per tile (uniform branch), not per element
     // GDN: beta joins the normalisation sums here, and the wavefront learns whether all of its operands are ordinary
     // numbers (common.h: the lean square root / division then replace the full IEEE sequences, same bits)
     bool lean = false;
@@ -288,7 +286,13 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[j][r] = acc2[j][r] + cbeta[j];
+        for (int q = 0; q < 4; ++q) {
+          const float4 be = *reinterpret_cast<const float4 *>(cquad + IC_CO + 32 * j + 8 * q);
+          acc2[j][4 * q + 0] = acc2[j][4 * q + 0] + be.x;
+          acc2[j][4 * q + 1] = acc2[j][4 * q + 1] + be.y;
+          acc2[j][4 * q + 2] = acc2[j][4 * q + 2] + be.z;
+          acc2[j][4 * q + 3] = acc2[j][4 * q + 3] + be.w;
+        }
       if (inv) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -310,38 +314,45 @@ __global__ __launch_bounds__(256, 2) void conv_images_kernel(ImgArgs a) {
       const uint32_t yb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(yb64 >> 32));  // (the builtin returns int:
       const uint32_t yb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)yb64);          //  no sign extension)
       // (a pointer rebuilt from integers has no address space: name it, or every store is a flat_store behind a 64-bit add)
-      typedef __attribute__((address_space(1))) float gfloat;
-      gfloat *yrow = reinterpret_cast<gfloat *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
-      const uint32_t lane_off = (uint32_t)(4 * hh * IC_CO + p);
+      typedef float gfloat4 __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(1))) gfloat4 ggfloat4;
+      typedef __attribute__((address_space(1))) char gchar;
+      gchar *yrow = reinterpret_cast<gchar *>((uintptr_t)(((uint64_t)yb_hi << 32) | (uint64_t)yb_lo));
+      // the lane's pixel is p; its accumulator quad q of block j is channels 32 j + 8 q + 4 hh .. + 3: one 16-byte store
+      const uint32_t lane_off = (uint32_t)(p * IC_CO + 4 * hh) * 4u;
       const int cols = a.wo - ox0;  // output columns of this tile that exist (>= 1)
       auto emit = [&](auto MODE, auto WHOLE, auto LEAN) {
         constexpr int MD = decltype(MODE)::value;  // 0 / 1 / 2: no GDN + none / leaky / relu, 3: GDN, 4: inverse GDN
         constexpr bool WH = decltype(WHOLE)::value;
         constexpr bool LN = decltype(LEAN)::value;
+        if (!WH && p >= cols) return;  // (per lane: a pixel beyond the image edge)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int mc = (r & 3) + 8 * (r >> 2);  // compile-time after unrolling
-            const int m = mc + 4 * hh;
-            float v = acc[j][r];
-            if constexpr (MD >= 3) {
-              if constexpr (LN) {
-                const float nrm = sqrt_rn_safe(acc2[j][r]);
-                v = MD == 4 ? v * nrm : div_rn_safe(v, nrm);
-              } else {
-                const float nrm = __builtin_sqrtf(acc2[j][r]);
-                v = MD == 4 ? v * nrm : v / nrm;
+          for (int q = 0; q < 4; ++q) {
+            float o4[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              const int r = 4 * q + st;
+              float v = acc[j][r];
+              if constexpr (MD >= 3) {
+                if constexpr (LN) {
+                  const float nrm = sqrt_rn_safe(acc2[j][r]);
+                  v = MD == 4 ? v * nrm : div_rn_safe(v, nrm);
+                } else {
+                  const float nrm = __builtin_sqrtf(acc2[j][r]);
+                  v = MD == 4 ? v * nrm : v / nrm;
+                }
               }
+              if constexpr (MD == 1) v = v > 0.0f ? v : v * 0.01f;
+              if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
+              o4[st] = v;
+              // keep the elements apart: interleaved sqrt / division sequences of many of them cost registers (the
+              // gamma fragments already take 64).  The lean ones go in pairs: the second element's instructions fill
+              // the wait state behind v_rsq / v_rcp (an s_nop otherwise)
+              if (!LN || (st & 1)) __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (MD == 1) v = v > 0.0f ? v : v * 0.01f;
-            if constexpr (MD == 2) v = v > 0.0f ? v : 0.0f;
-            if (WH || m < cols) yrow[lane_off + (uint32_t)(mc * IC_CO + 32 * j)] = v;
-            // keep the elements apart: interleaved sqrt / division sequences of many of them cost registers (the
-            // gamma fragments already take 64); a barrier every 2 / 4 / 16 elements measured the same with the full
-            // sequences.  The lean ones go in pairs: the second element's instructions fill the wait state behind
-            // v_rsq / v_rcp (an s_nop otherwise)
-            if (!LN || (r & 1)) __builtin_amdgcn_sched_barrier(0);
+            *reinterpret_cast<ggfloat4 *>(yrow + lane_off + (uint32_t)((32 * j + 8 * q) * 4)) = (gfloat4){o4[0], o4[1], o4[2], o4[3]};
           }
         }
       };
