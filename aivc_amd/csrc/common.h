@@ -56,7 +56,7 @@ __device__ __forceinline__ float act_apply(int act, float v) {
 //   sqrt_rn_safe  is the reciprocal-square-root refinement LLVM uses for an IEEE sqrt when fp32 denormals are flushed
 //                 (two coupled Newton steps and a final residual correction): correctly rounded, hence the same bits as
 //                 __builtin_sqrtf -- checked EXHAUSTIVELY over every float in the range by aivc_selfcheck_gdn_math
-//                 (tests/test_gpu_ops.py), which also compares div_rn_safe with operator/ on 2^34 random operand pairs.
+//                 (tests/test_gpu_ops.py), which also compares div_rn_safe with operator/ on 2^39 random operand pairs.
 // Measured (round 5, experiments/r05.md 11): the image layer 3.67 -> 3.49 ms (1 image) / 5.47 -> 5.26 ms (2 images) per
 // 32 frames of 1080p; the same change in the fused-GDN epilogues of conv_mfma.hip measured NOTHING (+-1 % on every shape,
 // even without the range check): those kernels hide their epilogue behind the other workgroups' K loops.  Not applied there.
