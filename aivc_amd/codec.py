@@ -26,6 +26,15 @@ def _stack(planes_list):
     return {k: torch.cat([p[k] for p in planes_list], dim=0) for k in 'yuv'}
 
 
+def _rows_of(entries):
+    """[(batch tensor, row), ...] -> the rows as one batch: a VIEW when they are consecutive rows of one tensor (the
+    frames of a dependency level sit together in the entropy stage's level-major launches), else a copy"""
+    t0, j0 = entries[0]
+    if all(t is t0 and j == j0 + i for i, (t, j) in enumerate(entries)):
+        return t0[j0:j0 + len(entries)]
+    return torch.cat([t[j:j + 1] for t, j in entries], dim=0)
+
+
 def _unstack(planes, n):
     return [{k: planes[k][i:i + 1] for k in 'yuv'} for i in range(n)]
 
@@ -498,7 +507,7 @@ class FrameCodec:
                         if v is not None:
                             v.record_stream(main)
                     for j, it in enumerate(chunk):
-                        lat[it] = {k: (None if v is None else v[j:j + 1]) for k, v in yh.items()}
+                        lat[it] = {k: (None if v is None else (v, j)) for k, v in yh.items()}  # (batch tensor, row)
                         ready[it] = evs
 
             def issue_entropy(level):
@@ -532,13 +541,14 @@ class FrameCodec:
                             for ev in ready[it]:
                                 main.wait_event(ev)
                             i, f = it
-                            rec[i][f] = self.synthesise_banded(lat[it], rec[i].get(gop[f]['prev_ref']),
+                            rec[i][f] = self.synthesise_banded({k: (None if e is None else e[0][e[1]:e[1] + 1]) for k, e in lat[it].items()},
+                                                               rec[i].get(gop[f]['prev_ref']),
                                                                rec[i].get(gop[f]['next_ref']), ftype, data_dim, bands)
                             del lat[it]
                 for ftype, chunk in ([] if banded else self._chunks(gop, level, members, shard)):
                     for ev in {id(e): e for it in chunk for e in ready[it]}.values():
                         main.wait_event(ev)
-                    yh = {k: (None if lat[chunk[0]][k] is None else torch.cat([lat[it][k] for it in chunk], dim=0))
+                    yh = {k: (None if lat[chunk[0]][k] is None else _rows_of([lat[it][k] for it in chunk]))
                           for k in ('mof', 'cod')}
                     dec = self.synthesise_batch(yh, [rec[i].get(gop[f]['prev_ref']) for i, f in chunk],
                                                 [rec[i].get(gop[f]['next_ref']) for i, f in chunk], ftype, data_dim)
