@@ -340,3 +340,19 @@ def test_truncated_container_is_an_error_not_garbage():
     assert split_sections(frame) == [b'', b'', b'abc', b'\x00']
     # the path API reads a section back while the later ones are not written yet (src/real_life/bitstream.py:333-350)
     assert split_sections(frame[:-5], upto=3) == [b'', b'', b'abc']
+
+
+def test_rows_of_is_a_view_for_consecutive_rows():
+    """codec._rows_of: the decoded latents of a synthesis batch are a view of the entropy stage's batch tensor when its
+    frames sit in consecutive rows, a copy otherwise -- the same values either way"""
+    import torch
+    from aivc_amd.codec import _rows_of
+    t = torch.arange(5 * 2 * 3 * 4, dtype=torch.float32).reshape(5, 2, 3, 4)
+    u = torch.arange(100, 100 + 2 * 2 * 3 * 4, dtype=torch.float32).reshape(2, 2, 3, 4)
+    v = _rows_of([(t, 1), (t, 2), (t, 3)])
+    assert v.data_ptr() == t[1:].data_ptr() and v.shape == (3, 2, 3, 4) and torch.equal(v, t[1:4])
+    c = _rows_of([(t, 3), (t, 1)])
+    assert torch.equal(c, torch.stack([t[3], t[1]])) and c.data_ptr() != t[3:].data_ptr()
+    m = _rows_of([(t, 4), (u, 0)])
+    assert torch.equal(m, torch.stack([t[4], u[0]]))
+    assert _rows_of([(u, 1)]).data_ptr() == u[1:].data_ptr()
