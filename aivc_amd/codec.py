@@ -11,7 +11,7 @@ import os as _os
 
 import torch
 
-from . import ops
+from . import abi, ops
 from .func_util.GOP_structure import FRAME_B, FRAME_I, FRAME_P, coding_levels, generate_gop_struct
 from .real_life import cat_binary_files as container
 from .real_life import header as hdr
@@ -315,21 +315,43 @@ class FrameCodec:
             ac.md5_errors = []
         return out
 
-    @staticmethod
-    def _entropy_bytes(parsed, members, data_dim):
+    def check_sections(self, parsed):
+        """The section framing and the y map lists of EVERY frame of every unit, on the host, before any kernel or
+        collective: a malformed file is then a ContainerError on every rank alike (each holds the whole bitstream) --
+        with the check left to decode_y only the rank that owns the bad frame raised while its peers went on into
+        the level's exchange and waited for the collective timeout."""
+        for u, (gop_name, _, frames) in enumerate(parsed):
+            gop = generate_gop_struct(gop_name)
+            names = sorted(gop, key=frame_index)
+            if len(names) != len(frames):
+                raise container.ContainerError('unit %d: %d frames in the record, coding structure %s has %d'
+                                               % (u, len(frames), gop_name, len(names)))
+            for k, fb in enumerate(frames):
+                secs = split_sections(fb)
+                for net, sy in ((self.mof, secs[1]), (self.cod, secs[3])):
+                    if net is self.mof and gop[names[k]]['type'] == FRAME_I:
+                        continue
+                    ac = getattr(net, 'ac', None)
+                    if ac is not None:
+                        ac._parse_maps(sy[32:] if ac.flag_md5sum else sy, net.nb_ft_y, k)
+
+    def _entropy_bytes(self, parsed, members, data_dim):
         """device bytes the entropy stage of these units holds when all of it is issued at once: per coded y symbol the
         64-entry CDF window + sigma (132 B, real_life/bitstream.py _rows_workspace) + the symbol, per frame the
         hyperprior's activations and latents (bounded by 64 floats per y position per network).  The coded map counts
-        are in the sections' first byte."""
+        are in the sections' first byte -- behind the 32-character md5 text under flag_md5sum
+        (ArithmeticCoder._strip_md5) -- and never more than the format's map limit."""
         h_y, w_y = data_dim['y']
         npix = h_y * w_y
         total = 0
         for i in members:
             for fb in parsed[i][2]:
                 secs = split_sections(fb)
-                for sy in (secs[1], secs[3]):
-                    if sy:
-                        total += sy[0] * npix * 134 + npix * 4 * 640
+                for net, sy in ((self.mof, secs[1]), (self.cod, secs[3])):
+                    ac = getattr(net, 'ac', None)
+                    skip = 32 if ac is not None and ac.flag_md5sum else 0
+                    if len(sy) > skip:
+                        total += min(sy[skip], abi.MAX_MAPS) * npix * 134 + npix * 4 * 640
         return total
 
     @staticmethod
@@ -462,6 +484,7 @@ class FrameCodec:
         range-coder streams run concurrently, one wavefront each; the serial coder is off the
         frame-to-frame critical path).  Stage 2 reconstructs level by level in batches."""
         parsed = [container.unpack_gop(g) for g in gop_blobs]
+        self.check_sections(parsed)
         out = [None] * len(gop_blobs)
         groups = {}
         for i, (name, idx_rate, _) in enumerate(parsed):
@@ -605,6 +628,8 @@ class FrameCodec:
         """-> list of uint8 plane dicts for frames idx_first..idx_last (padded frames removed);
         frames of units filtered out are None."""
         data_dim, first, last, gops = container.unpack_video(blob)
+        if unit_filter is not None:
+            self.check_sections([container.unpack_gop(g) for g in gops])  # (every rank: the units of its peers as well)
         mine = [u for u in range(len(gops)) if unit_filter is None or unit_filter(u)]
         dec = dict(zip(mine, self.decode_units([gops[u] for u in mine], data_dim, device))) if mine else {}
         frames = []

@@ -409,6 +409,8 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
 
 static bool thin_mfma_ok(const aivc_conv_params &p) {
   if (p.c_in != 16 && p.c_in != 32 && p.c_in != 64) return false;  // instantiated widths (B operand in registers)
+  // an image is addressed through a buffer descriptor with signed 32-bit byte offsets: larger ones go to the VALU kernel
+  if ((uint64_t)p.h_in * (uint64_t)p.w_in * (uint64_t)p.c_in * 4u >= 0x7FFFFFC0ull) return false;
   return p.act1 != AIVC_ACT_SIGMOID && p.act2 != AIVC_ACT_SIGMOID;
 }
 

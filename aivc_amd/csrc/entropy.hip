@@ -1109,6 +1109,9 @@ AIVC_EXPORT int aivc_range_encode(const uint32_t *bounds, const aivc_rc_batch *b
   if (batch->n_streams == 0) return AIVC_OK;
   for (int i = 0; i < batch->n_streams; ++i) {
     if (batch->s[i].out_off % 4) return AIVC_ERR_ARG;
+    // whole 32-bit words only (both encoders store words), and at least one: the lane packer's last-word clamp is
+    // out_cap / 4 - 1
+    if (batch->s[i].out_cap < 4 || batch->s[i].out_cap % 4) return AIVC_ERR_ARG;
     if (batch->s[i].n_sym && !bounds) return AIVC_ERR_ARG;
   }
   // one stream per lane (one wavefront for the whole batch) unless AIVC_RC_ENCODE=wave asks for the wave-per-stream kernel

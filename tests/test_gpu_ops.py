@@ -308,6 +308,44 @@ def test_range_encoder_batches_ragged_streams_and_long_straddle_runs(kernel, ora
         assert out_h[off:off + int(n)].tobytes() == w, (kernel, i, lens[i])
 
 
+@pytest.mark.parametrize('kernel', ['lanes', 'wave'])
+def test_range_encoder_output_capacity_contract(kernel, oracle, cuda, monkeypatch):
+    """include/aivc_hip.h aivc_rc_stream.out_cap: whole 32-bit words, at least one -- anything else is AIVC_ERR_ARG at the
+    entry point (the stream-per-lane packer clamps its stores to word out_cap / 4 - 1); a capacity the stream does not
+    fit reports out_len 0xFFFFFFFF and writes nothing beyond it"""
+    import ctypes as C
+    from aivc_amd import abi, ops
+    from aivc_amd._lib import AivcNativeError, call
+    monkeypatch.setenv('AIVC_RC_ENCODE', kernel)
+    rng = np.random.default_rng(5)
+    bounds = _straddle_stream(rng, 400, burst=3)
+    want = oracle.range_encode(bounds)
+    assert len(want) > 64
+    b = T(np.ascontiguousarray(bounds).view(np.int32), cuda)
+    guard = 0xA5
+    for cap, ok in ((0, False), (3, False), (6, False), (8, True), (64, True), ((len(want) + 3) // 4 * 4, True)):
+        out = torch.full((4096,), guard, dtype=torch.uint8, device=cuda)
+        ln = torch.zeros(1, dtype=torch.int32, device=cuda)
+        batch = abi.RcBatch()
+        batch.n_streams = 1
+        batch.s[0].in_off, batch.s[0].out_off, batch.s[0].n_sym, batch.s[0].out_cap = 0, 0, b.numel(), cap
+        args = ('aivc_range_encode', C.c_void_p(b.data_ptr()), C.byref(batch), C.c_void_p(out.data_ptr()),
+                C.c_void_p(ln.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if not ok:
+            with pytest.raises(AivcNativeError):
+                call(*args)
+            continue
+        call(*args)
+        torch.cuda.synchronize()
+        n = int(ln.cpu().numpy().view(np.uint32)[0])
+        out_h = out.cpu().numpy()
+        assert (out_h[cap:] == guard).all(), (kernel, cap)  # nothing beyond the capacity
+        if cap >= len(want):
+            assert n == len(want) and out_h[:n].tobytes() == want
+        else:
+            assert n == 0xFFFFFFFF, (kernel, cap, n)
+
+
 @pytest.mark.parametrize('scale', [0.4, 3.0, 40.0, 150.0])
 def test_range_decode_from_windows(scale, oracle, cuda):
     """64-entry CDF windows + sigma per position (what the codec's decoder reads) give the symbols of the full rows,

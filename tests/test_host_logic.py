@@ -356,3 +356,48 @@ def test_rows_of_is_a_view_for_consecutive_rows():
     m = _rows_of([(t, 4), (u, 0)])
     assert torch.equal(m, torch.stack([t[4], u[0]]))
     assert _rows_of([(u, 1)]).data_ptr() == u[1:].data_ptr()
+
+
+def _fake_codec(c_y=8, md5=False):
+    """what FrameCodec.check_sections / _entropy_bytes read of a codec: two networks with an ArithmeticCoder each"""
+    from types import SimpleNamespace
+    from aivc_amd.real_life.bitstream import ArithmeticCoder
+    ac = SimpleNamespace(flag_md5sum=md5, _parse_maps=ArithmeticCoder._parse_maps)
+    net = SimpleNamespace(ac=ac, nb_ft_y=c_y)
+    return SimpleNamespace(mof=net, cod=SimpleNamespace(ac=ac, nb_ft_y=c_y))
+
+
+def _frame(mof_y, cod_y):
+    return b''.join(len(s).to_bytes(4, 'big') + s for s in (b'z', mof_y, b'z', cod_y))
+
+
+def test_map_lists_of_every_frame_are_checked_before_any_rank_starts():
+    """FrameCodec.check_sections: a y section whose map list is malformed is a ContainerError for the WHOLE container on
+    the host (every rank holds the bitstream and fails alike) -- not only on the rank that decodes the frame"""
+    from aivc_amd.codec import FrameCodec
+    from aivc_amd.real_life import cat_binary_files as container
+    good = _frame(b'\x02\x00\x03ab', b'\x01\x07c')
+    parsed = [('1_GOP_2', 0., [_frame(b'', b'\x00'), good, good])]
+    FrameCodec.check_sections(_fake_codec(), parsed)
+    for bad in (_frame(b'\x02\x00', b'\x00'),          # two maps announced, one listed
+                _frame(b'\x01\x09x', b'\x00'),         # map 9 of 8
+                _frame(b'\x00', b''),                  # no map count at all
+                _frame(b'\x00', b'\x09' + bytes(9))):  # more maps than the latent has
+        with pytest.raises(container.ContainerError):
+            FrameCodec.check_sections(_fake_codec(), [('1_GOP_2', 0., [_frame(b'', b'\x00'), good, bad])])
+    # the I frame's MOFNet section is not read (nothing decodes it)
+    FrameCodec.check_sections(_fake_codec(), [('1_GOP_2', 0., [_frame(b'\x63', b'\x00'), good, good])])
+    # under flag_md5sum the list sits behind the 32 characters of the digest
+    md5 = b'0' * 32
+    FrameCodec.check_sections(_fake_codec(md5=True), [('1_GOP_2', 0., [_frame(b'', md5 + b'\x00')] + [_frame(md5 + b'\x01\x02q', md5 + b'\x00')] * 2)])
+
+
+def test_entropy_memory_estimate_reads_the_map_count_behind_the_md5_text():
+    from aivc_amd.codec import FrameCodec
+    dd = {'x': (64, 64), 'y': (4, 4), 'z': (1, 1)}
+    plain = [('1_GOP_0', 0., [_frame(b'', b'\x03\x00\x01\x02xyz')])]
+    md5 = b'f' * 32  # ('f' = 102 as a map count)
+    tagged = [('1_GOP_0', 0., [_frame(b'', md5 + b'\x03\x00\x01\x02xyz')])]
+    a = FrameCodec._entropy_bytes(_fake_codec(), plain, [0], dd)
+    b = FrameCodec._entropy_bytes(_fake_codec(md5=True), tagged, [0], dd)
+    assert a == b == 3 * 16 * 134 + 16 * 4 * 640
