@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 PREC_FP32, PREC_BF16X3 = 0, 1  # aivc_conv_params.precision
 
 AIVC_OK = 0
@@ -25,6 +25,7 @@ CDF_WIN0, CDF_WIN = 224, 64  # the decoder's fast-path window of a CDF row
 BALLE_PARAMS = 43
 MAX_MAPS = 256
 RC_MAX_STREAMS = 64
+RATE_LANES = 16384
 
 FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 
@@ -133,6 +134,10 @@ PROTOTYPES = {
     'aivc_laplace_bounds_batch': [_f, _f, _i32, _sz, _i32, _f, _i32, _f],
     'aivc_table_bounds_batch': [_f, _f, _i32, _sz, _i32, _f],
     'aivc_scatter_symbols_batch': [_f, _i32, _sz, _i32, _f, _f],
+    'aivc_bounds_rate': [_f, _sz, _f, _f],
+    'aivc_rate_bits': [_f, _sz, _fl, _fl, _f, _f, _f],
+    'aivc_laplace_prob': [_f, _f, _f, _sz, _f],
+    'aivc_table_prob': [_f, _f, _sz, _sz, _i32, _f],
 }
 
 

@@ -467,6 +467,10 @@ class FrameCodec:
         for items, job in jobs:
             for (u, f), b in zip(items, job.collect()):
                 fbytes[u][f] = b
+            # (logging, real_life.bitstream.ESTIMATE_RATE: what the CDF bounds price this rank's streams at, and what the
+            # range coder wrote for them)
+            self.estimated_bits = getattr(self, 'estimated_bits', 0.0) + job.est_bits
+            self.coded_payload_bytes = getattr(self, 'coded_payload_bytes', 0) + job.real_bytes
         if split:
             keys = [(u, f) for u in range(len(units)) for f in names]
             allb = shard.gather_bytes({k: fbytes[k[0]][k[1]] for k in keys if k[1] in fbytes[k[0]]}, keys)

@@ -3,7 +3,7 @@
 BallePdfEstim holds the factorised-prior parameters (`matrix_h.{0..3}`, `bias_a.{0..2}`,
 `bias_b.{0..3}`) exactly like the reference; what the codec needs from it -- the CDF at the 514
 half-integer points -- is produced by the aivc_balle_cdf_table kernel.  ParametricPdf is kept for
-pickle compatibility (rate *estimation* is training/logging, out of the coded path)."""
+pickle compatibility and rate estimation (logging: aivc_laplace_prob / aivc_table_prob, csrc/rate.hip)."""
 import torch
 from torch import nn
 
@@ -24,8 +24,19 @@ class ParametricPdf(nn.Module):
         self.pdf_family = pdf_family
 
     def forward(self, y_tilde, all_pdf_param, zero_mu=False):
-        raise NotImplementedError('rate estimation is not part of the encode/decode hot path; the '
-                                  'real rate is the bitstream size')
+        """p(y_tilde) = sum over the mixture components of cdf(y + .5) - cdf(y - .5)
+        (src/layers/entropy_coding/pdf_estimator.py:27-65); Laplace family (what the coded path uses:
+        src/real_life/bitstream.py:127-154), evaluated by aivc_laplace_prob.  Rate estimation / logging only."""
+        fam = self.pdf_family.split('_')
+        if 'laplace' not in fam:
+            raise NotImplementedError('ParametricPdf.forward: family %r (the coded path is Laplace)' % self.pdf_family)
+        p = None
+        for pdf_param in all_pdf_param:
+            mu = None if ('mu' in fam or zero_mu) else pdf_param.get('mu')
+            sigma = pdf_param.get('sigma').expand_as(y_tilde)
+            cur = ops.laplace_prob(y_tilde, None if mu is None else mu.expand_as(y_tilde), sigma)
+            p = cur if p is None else p + cur
+        return p
 
 
 class BallePdfEstim(nn.Module):
@@ -78,4 +89,10 @@ class BallePdfEstim(nn.Module):
         return cdf.reshape(1, self.nb_channel, abi.LP, 1)
 
     def forward(self, x_tilde, pdf_param=None):
-        raise NotImplementedError('rate estimation is not part of the encode/decode hot path')
+        """p(x_tilde) = cdf(x + .5) - cdf(x - .5) (src/layers/entropy_coding/pdf_estimator.py:185-202) for the
+        integer-valued latents of inference, [B, C, H, W]: both points are entries of the 514-point table
+        (aivc_table_prob); values that are not codable symbols give NaN.  Rate estimation / logging only."""
+        if 'sigma' in self.pdf_family.split('_'):
+            raise NotImplementedError('BallePdfEstim.forward: the sigma-scaled family is not used by the codec')
+        _, cdf = self.cdf_table(x_tilde.device, want_float=True)
+        return ops.table_prob(x_tilde, cdf)

@@ -672,6 +672,55 @@ def table_bounds(table, q):
     return bounds
 
 
+# ---- rate estimation (logging only; csrc/rate.hip) ---------------------------------------------------------
+def _rate_scratch(device, out=None):
+    lanes = torch.empty(abi.RATE_LANES, dtype=torch.float64, device=device)
+    return lanes, (torch.empty(1, dtype=torch.float64, device=device) if out is None else out)
+
+
+def bounds_rate(bounds, out=None):
+    """packed CDF bounds (laplace_bounds / table_bounds) -> device fp64 [1]: the bits the range coder pays for them
+    (sum of -log2((c_hi - c_lo) / 2^16), fixed summation order).  No sync.  out: a 1-element fp64 view to fill."""
+    bounds = _dev(bounds, torch.int32, 'bounds')
+    lanes, out = _rate_scratch(bounds.device, out)
+    call('aivc_bounds_rate', _p(bounds), bounds.numel(), _p(lanes), _p(out), _stream())
+    return out
+
+
+def rate_bits(prob, p_min, p_max):
+    """EntropyCoder.forward (src/layers/entropy_coding/entropy_coder.py:25-30): -log2(clamp(prob)) -> (rate like prob,
+    device fp64 [1] sum)"""
+    prob = _dev(prob, torch.float32, 'prob')
+    rate = torch.empty_like(prob)
+    lanes, out = _rate_scratch(prob.device)
+    call('aivc_rate_bits', _p(prob), prob.numel(), float(p_min), float(p_max), _p(rate), _p(lanes), _p(out), _stream())
+    return rate, out
+
+
+def laplace_prob(y, mu, sigma):
+    """P(bin of y) under Laplace(mu, sigma / sqrt(2)) elementwise (mu None = 0), ParametricPdf.forward"""
+    y = _dev(y, torch.float32, 'y')
+    sigma = _dev(sigma, torch.float32, 'sigma')
+    mu = _dev(mu, torch.float32, 'mu')
+    if sigma.shape != y.shape or (mu is not None and mu.shape != y.shape):
+        raise AivcNativeError('aivc_amd.ops.laplace_prob: y, mu and sigma must have one shape')
+    prob = torch.empty_like(y)
+    call('aivc_laplace_prob', _p(y), _p(mu), _p(sigma), y.numel(), _p(prob), _stream())
+    return prob
+
+
+def table_prob(x, cdf_f32):
+    """x [b, c, h, w] integer-valued in [-256, 256], cdf_f32 [c, 514] (balle_cdf_table(want_float=True)) -> P(bin of x)"""
+    x = _dev(x, torch.float32, 'x')
+    cdf_f32 = _dev(cdf_f32, torch.float32, 'cdf_f32')
+    b, c, h, w = x.shape
+    if tuple(cdf_f32.shape) != (c, abi.LP):
+        raise AivcNativeError('aivc_amd.ops.table_prob: cdf table %s for %d channels' % (tuple(cdf_f32.shape), c))
+    prob = torch.empty_like(x)
+    call('aivc_table_prob', _p(x), _p(cdf_f32), x.numel(), h * w, c, _p(prob), _stream())
+    return prob
+
+
 _STAGING = []  # [(event or None, pinned uint8 tensor)]
 
 

@@ -104,12 +104,20 @@ def _unpin(t):
     _PIN_POOL.setdefault((base.dtype, base.numel()), []).append(base)
 
 
+# In-band rate check of the reference (src/real_life/bitstream.py:307-329, RESULT lines of src/real_life/encode.py:
+# 153-170): with ESTIMATE_RATE on, every range-encoder stream also gets the bits its CDF bounds price it at
+# (aivc_bounds_rate, one small launch per stream behind the bounds kernels, off the main stream) -- EntropyJob.est_bits.
+# Off by default: logging only.
+ESTIMATE_RATE = False
+
+
 class EntropyJob:
     """Range-encode launches of a set of frames, possibly still running on a side stream."""
 
-    def __init__(self, n_frames, present, heads, jobs, out_h, lens_h, offs, event, keep):
+    def __init__(self, n_frames, present, heads, jobs, out_h, lens_h, offs, event, keep, est_h=None):
         self.n_frames, self.present, self.heads, self.jobs = n_frames, present, heads, jobs
         self.out_h, self.lens_h, self.offs, self.event, self.keep = out_h, lens_h, offs, event, keep
+        self.est_h, self.est_bits, self.real_bytes = est_h, 0.0, 0
 
     def collect(self):
         """-> list of frame byte strings (waits for the side stream)."""
@@ -121,6 +129,11 @@ class EntropyJob:
                 if int(ln) < 0:
                     raise RuntimeError('range encoder output buffer overflow')
                 payload[fi][si] = out_h[off:off + int(ln)].tobytes()
+            if self.est_h is not None:
+                self.est_bits = float(self.est_h.numpy().sum())
+                self.real_bytes = int(lens_h.sum())
+                _unpin(self.est_h)
+                self.est_h = None
         frames = []
         for fi in range(self.n_frames):
             blob = b''
@@ -232,9 +245,16 @@ def launch_finalize(frames_sections, side_stream=None, prepared=None, fork_strea
             for fi, si, s in sorted(members, key=lambda m: m[2].batch[2]):
                 jobs.append((fi, si))
                 bounds.append(zb[s.batch[2]])
-        out_h = lens_h = offs = event = None
+        out_h = lens_h = offs = event = est_h = None
         keep = [frames_sections, bounds]
         if jobs:
+            if ESTIMATE_RATE:
+                est = torch.empty(len(bounds), dtype=torch.float64, device=bounds[0].device)
+                for j, b in enumerate(bounds):
+                    ops.bounds_rate(b, out=est[j:j + 1])
+                est_h = _pinned(est.numel(), torch.float64, floor=64)
+                est_h.copy_(est, non_blocking=True)
+                keep.append(est)
             out, lens, offs = ops.range_encode(bounds, streams=fork_streams)
             out_h = _pinned(out.numel(), torch.uint8)
             lens_h = _pinned(lens.numel(), torch.int32)
@@ -246,7 +266,7 @@ def launch_finalize(frames_sections, side_stream=None, prepared=None, fork_strea
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
-    return EntropyJob(len(frames_sections), present, heads, jobs, out_h, lens_h, offs, event, keep)
+    return EntropyJob(len(frames_sections), present, heads, jobs, out_h, lens_h, offs, event, keep, est_h)
 
 
 def finalize_frames(frames_sections):
@@ -478,23 +498,18 @@ class ArithmeticCoder():
 
     def _debug_report(self, x, sigma, mode, body, nbytes_written, path, latent_name, param):
         """flag_debug of the reference (src/real_life/bitstream.py:306-350): estimated against real rate, then
-        a decode of what was just written.  Debug path: plain torch on the device, one sync."""
+        a decode of what was just written.  Debug path: the rate-estimation kernels (csrc/rate.hip), one sync."""
         md5 = 32 if param.get('flag_md5sum', False) else 0
         if mode == 'laplace':
             nb_sent = body[md5]
             header_overhead = md5 + 1 + nb_sent
-            b = sigma / torch.sqrt(torch.tensor([2.0], device=x.device))
-            pdf = torch.distributions.Laplace(torch.zeros_like(b), b)
-            proba = torch.clamp(pdf.cdf(x + 0.5) - pdf.cdf(x - 0.5), 2 ** -16, 1.)
+            proba = ops.laplace_prob(x.float(), None, sigma.expand_as(x))
         else:
             nb_sent = x.shape[1]
             header_overhead = md5
-            _, cdf = self.balle_pdf_estim.cdf_table(x.device, want_float=True)  # [C, 514] at k - 256.5
-            idx = (x.long() + self.AC_MAX_VAL)[0]  # [C, h, w]
-            c = cdf.reshape(x.shape[1], abi.LP)
-            ar = torch.arange(x.shape[1], device=x.device)[:, None, None]
-            proba = torch.clamp(c[ar, idx + 1] - c[ar, idx], 2 ** -16, 1.)
-        estimated_rate = (-torch.log2(proba).sum() / 8000).item() + 1e-3
+            proba = self.balle_pdf_estim(x.float())
+        _, bits = ops.rate_bits(proba, 2 ** -16, 1.)
+        estimated_rate = float(bits.cpu()) / 8000 + 1e-3
         real_rate = (len(body) + 4) / 1000
         print('Arithmetic coding of      : ' + str(path.split('/')[-1].rstrip(BITSTREAM_SUFFIX)) + ' ' + latent_name)
         print('Number of ft. maps sent   : ' + str(nb_sent))

@@ -55,7 +55,10 @@ def encode(param):
     print_log_msg('INFO', 'Start encoding', '', '')
     t0 = time.time()
     fc = FrameCodec(model)
+    from . import bitstream
     from .. import parallel
+    keep_flag, bitstream.ESTIMATE_RATE = bitstream.ESTIMATE_RATE, True  # the reference's in-band rate check (RESULT lines)
+    fc.estimated_bits, fc.coded_payload_bytes = 0.0, 0
     rank, world = parallel.rank_world()
     with torch.no_grad():
         if world > 1:  # one process per GPU: intra-period units over the ranks, the container on rank 0
@@ -66,8 +69,10 @@ def encode(param):
                                   idx_rate=get_value('idx_rate', param, default))
             blob = fc.assemble_video(enc)
     torch.cuda.synchronize()
+    bitstream.ESTIMATE_RATE = keep_flag
     dt = time.time() - t0
     n = last - first + 1
+    est_bits, payload = fc.estimated_bits, float(fc.coded_payload_bytes)
     # squared error of the frames THIS process reconstructed (all of them on one GPU), summed over the ranks
     se = cnt = 0.0
     mine = []  # (absolute frame index, reconstruction)
@@ -82,9 +87,9 @@ def encode(param):
                 cnt += sum(frames[idx][k].numel() for k in 'yuv')
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([se, cnt], dtype=torch.float64, device=parallel._comm_device(None, dev))
+        t = torch.tensor([se, cnt, est_bits, payload], dtype=torch.float64, device=parallel._comm_device(None, dev))
         dist.all_reduce(t)
-        se, cnt = float(t[0]), float(t[1])
+        se, cnt, est_bits, payload = (float(v) for v in t)
     if get_value('flag_bitstream_debug', param, default):
         from .decode import debug_dir, write_debug_md5
         for idx, r in mine:  # every rank writes the digests of its own frames
@@ -106,5 +111,15 @@ def encode(param):
     print_log_msg('RESULT', 'Encoding/decoding time', '[s]', '%.1f' % dt)
     print_log_msg('RESULT', 'Encoding/decoding FPS', '[frame/s]', '%.1f' % (n / dt))
     print_log_msg('RESULT', 'Estimated PSNR', '[dB]', '%.4f' % psnr)
+    # The reference's in-band rate check (src/real_life/encode.py:140-170): the rate its entropy model ESTIMATES against
+    # the bytes written.  Here the estimate is what the 16-bit CDF bounds price the coded symbols at (aivc_bounds_rate:
+    # sum of -log2((c_hi - c_lo) / 2^16), what an ideal arithmetic coder would write for the same CDFs); the real rate
+    # is the file, whose overhead over the estimate is the range coder's flush (< 2 bytes per stream), the map lists
+    # and the container's length prefixes and headers.
+    est_byte = est_bits / 8
+    overhead = (len(blob) / est_byte - 1) * 100 if est_byte > 0 else float('nan')
+    print_log_msg('RESULT', 'Estimated rate', '[byte]', '%.1f' % est_byte)
     print_log_msg('RESULT', 'Real rate', '[byte]', len(blob))
-    return {'real_rate_byte': len(blob), 'psnr': psnr, 'nb_frames_to_code': n}
+    print_log_msg('RESULT', 'Estimated rate overhead', '[%]', '%.2f' % overhead)
+    return {'real_rate_byte': len(blob), 'psnr': psnr, 'nb_frames_to_code': n, 'estimated_rate_byte': est_byte,
+            'rate_overhead_percent': overhead, 'range_coder_payload_byte': int(payload)}

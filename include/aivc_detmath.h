@@ -245,4 +245,36 @@ AIVC_HD uint16_t aivc_laplace_cdf_u16_scale(int k, float b) {
   return aivc_cdf_quant(0.5f - hs * e, k);
 }
 
+/* ---- rate estimation (logging only; csrc/rate.hip) ---------------------------------------------------------------
+ * -log2 of a probability, the reference's EntropyCoder.forward (src/layers/entropy_coding/entropy_coder.py:25-30):
+ * clamp(p, p_min, p_max) then -log2, one rounding to fp32. */
+AIVC_HD float aivc_rate_of_prob(float p, float p_min, float p_max) {
+  const float c = p < p_min ? p_min : (p > p_max ? p_max : p); /* (a NaN stays a NaN, as torch.clamp) */
+  if (!(c == c)) return c;
+  return (float)(-(aivc_det_log((double)c) * 1.4426950408889634)); /* 1 / ln 2 */
+}
+/* bits the range coder pays for a symbol whose CDF bounds are packed as aivc_laplace_bounds / aivc_table_bounds pack
+ * them (c_lo | c_hi << 16, c_hi = 0 meaning 2^16): -log2((c_hi - c_lo) / 2^16), fp64 */
+AIVC_HD double aivc_rate_of_bounds(uint32_t b) {
+  const uint32_t lo = b & 0xFFFFu, hi16 = b >> 16;
+  const uint32_t hi = hi16 ? hi16 : 0x10000u;
+  if (hi <= lo) return 16.0; /* not a codable symbol: priced as the smallest probability */
+  return 16.0 - aivc_det_log((double)(hi - lo)) * 1.4426950408889634;
+}
+/* P(bin of y) under Laplace(mu, sigma/sqrt(2)): cdf(y + .5) - cdf(y - .5) in the reference's fp32 op order
+ * (ParametricPdf.forward, src/layers/entropy_coding/pdf_estimator.py:52-63) */
+AIVC_HD float aivc_laplace_bin_prob(float y, float mu, float sigma) {
+  const float up = (y + 0.5f) - mu, dn = (y - 0.5f) - mu;
+  return aivc_laplace_cdf(up, sigma) - aivc_laplace_cdf(dn, sigma);
+}
+/* P(bin of x) from a row of the factorised prior's CDF at k - 256.5, k = 0..513 (BallePdfEstim.forward,
+ * src/layers/entropy_coding/pdf_estimator.py:196-202, for the integer-valued x of inference): x + .5 is point x + 257,
+ * x - .5 point x + 256; values outside [-256, 256] (not codable) or not integers give NaN */
+AIVC_HD float aivc_table_bin_prob(float x, const float *cdf_row) {
+  if (!(x >= -256.0f && x <= 256.0f)) return __builtin_nanf("");
+  const int k = (int)x;
+  if ((float)k != x) return __builtin_nanf("");
+  return cdf_row[k + 257] - cdf_row[k + 256];
+}
+
 #endif /* AIVC_DETMATH_H */

@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 14
+#define AIVC_ABI_VERSION 15
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -420,6 +420,29 @@ int aivc_table_bounds_batch(const uint16_t *table, const int16_t *q, int32_t n, 
 /* q[f][pix][frames[f].idx[m]] = sym[frames[f].pos_off + m * npix + pix] - 256, every other channel 0 */
 int aivc_scatter_symbols_batch(const uint16_t *sym, int32_t n, size_t npix, int32_t c,
                                const aivc_frame_maps *frames, int16_t *q, aivc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rate estimation (ABI 15) -- logging only, never on the coded path.  The reference prints an estimated rate next to
+ * the real one: per section under flag_debug (src/real_life/bitstream.py:307-329), per video in the RESULT lines
+ * (src/real_life/encode.py:153-170), from the probabilities of its entropy models
+ * (src/layers/entropy_coding/entropy_coder.py:18-30, pdf_estimator.py:27-65 and :185-202).
+ * Sums are fp64 and deterministic: lane j of AIVC_RATE_LANES adds elements j, j + L, ... in order, then
+ * lanes[j] += lanes[j + s] for s = L/2 .. 1.  `lanes` is caller-owned scratch of AIVC_RATE_LANES doubles.
+ * ---------------------------------------------------------------------------------------- */
+#define AIVC_RATE_LANES 16384
+/* sum[0] = sum over the n packed bounds (aivc_laplace_bounds / aivc_table_bounds) of -log2((c_hi - c_lo) / 2^16): the bits
+ * the range coder pays for exactly the CDFs it codes with */
+int aivc_bounds_rate(const uint32_t *bounds, size_t n, double *lanes, double *sum, aivc_stream_t stream);
+/* EntropyCoder.forward: rate[i] = -log2(clamp(prob[i], p_min, p_max)) (rate may be NULL); sum[0] = their fp64 sum */
+int aivc_rate_bits(const float *prob, size_t n, float p_min, float p_max, float *rate, double *lanes, double *sum,
+                   aivc_stream_t stream);
+/* ParametricPdf.forward, Laplace family, one component: prob[i] = cdf(y + .5) - cdf(y - .5) under
+ * Laplace(mu[i], sigma[i] / sqrt(2)); mu NULL = 0 */
+int aivc_laplace_prob(const float *y, const float *mu, const float *sigma, size_t n, float *prob, aivc_stream_t stream);
+/* BallePdfEstim.forward for integer-valued x in [-256, 256], x laid out [b][c][hw] (NCHW, n = b*c*hw elements):
+ * prob[i] = cdf_f32[ch][x + 257] - cdf_f32[ch][x + 256] with cdf_f32 [c][AIVC_LP] from aivc_balle_cdf_table; NaN for
+ * values that are not codable symbols */
+int aivc_table_prob(const float *x, const float *cdf_f32, size_t n, size_t hw, int32_t c, float *prob, aivc_stream_t stream);
 
 /* ---- quality metrics, fp64 planes [n][h][w] on the device -------------------------
  * Scratch for the three calls below, in bytes (for the largest plane they will see). */

@@ -434,6 +434,41 @@ def table_bounds(table, q):
     return bounds
 
 
+def bounds_rate(bounds):
+    """bits the range coder pays for these packed CDF bounds (sum of -log2 of the coded probabilities, fp64)"""
+    bounds = np.ascontiguousarray(bounds, np.uint32)
+    lanes, out = np.zeros(abi.RATE_LANES, np.float64), np.zeros(1, np.float64)
+    _chk(lib()['aivc_bounds_rate'](_p(bounds) if bounds.size else None, bounds.size, _p(lanes), _p(out), None), 'aivc_bounds_rate')
+    return float(out[0])
+
+
+def rate_bits(prob, p_min, p_max):
+    """EntropyCoder.forward -> (rate fp32 like prob, fp64 sum)"""
+    prob = np.ascontiguousarray(prob, np.float32)
+    rate = np.empty_like(prob)
+    lanes, out = np.zeros(abi.RATE_LANES, np.float64), np.zeros(1, np.float64)
+    _chk(lib()['aivc_rate_bits'](_p(prob), prob.size, p_min, p_max, _p(rate), _p(lanes), _p(out), None), 'aivc_rate_bits')
+    return rate, float(out[0])
+
+
+def laplace_prob(y, mu, sigma):
+    y = np.ascontiguousarray(y, np.float32)
+    sigma = np.ascontiguousarray(sigma, np.float32)
+    mu = None if mu is None else np.ascontiguousarray(mu, np.float32)
+    prob = np.empty_like(y)
+    _chk(lib()['aivc_laplace_prob'](_p(y), None if mu is None else _p(mu), _p(sigma), y.size, _p(prob), None), 'aivc_laplace_prob')
+    return prob
+
+
+def table_prob(x, cdf_f32):
+    """x [b, c, h, w] integer-valued floats, cdf_f32 [c, 514] -> probabilities [b, c, h, w]"""
+    x = np.ascontiguousarray(x, np.float32)
+    cdf_f32 = np.ascontiguousarray(cdf_f32, np.float32)
+    prob = np.empty_like(x)
+    _chk(lib()['aivc_table_prob'](_p(x), _p(cdf_f32), x.size, x.shape[2] * x.shape[3], x.shape[1], _p(prob), None), 'aivc_table_prob')
+    return prob
+
+
 def range_encode(bounds):
     """one stream -> bytes"""
     bounds = np.ascontiguousarray(bounds, np.uint32)

@@ -389,6 +389,18 @@ def test_cli_encode_decode_evaluate(cuda, tmp_path, capsys):
             ms += 0.0 if np.isnan(v) else v  # metrics.py:40-45: a NaN score counts as zero
     assert abs(vals['PSNR    [dB]'] - (20 * np.log10(255.) - 10 * np.log10(sq / num))) < 1e-4  # 5 printed decimals
     assert abs(vals['MS-SSIM     '] - ms / num) < 1e-5
+    # the reference's in-band rate check (src/real_life/encode.py:153-170): estimated rate next to the real one
+    res = {}
+    for line in printed.splitlines():
+        for key in ('Estimated rate overhead', 'Estimated rate', 'Real rate'):
+            if '[RESULT]' in line and key in line and key not in res:
+                res[key] = float(line.split()[-1])
+                break
+    assert res['Real rate'] == os.path.getsize(bits)
+    # the file = what the CDFs price the symbols at + flush bytes, map lists, length prefixes, headers: a few per cent
+    # on a clip this small, and never less
+    assert 0 < res['Estimated rate'] < res['Real rate'] < 1.5 * res['Estimated rate'] + 2048
+    assert abs(res['Estimated rate overhead'] - (res['Real rate'] / res['Estimated rate'] - 1) * 100) < 0.02
 
 
 def test_md5_debug_sections(cuda):

@@ -159,3 +159,53 @@ def test_balle_cdf_table(i, cuda, golden):
     ref16 = ((np.rint(g['cdf'] * np.float32(65023)).astype(np.int64) + np.arange(514)) & 0xFFFF)
     diff = np.abs(table.cpu().numpy().view(np.uint16)[:, :514].astype(np.int64) - ref16)
     assert diff.max() <= 1 and (diff != 0).mean() < 0.01
+
+
+def test_rate_estimation_modules(cuda, golden, oracle):
+    """EntropyCoder / ParametricPdf / BallePdfEstim forward (logging only) on the HIP kernels of csrc/rate.hip: against
+    the reference's outputs (rate_est_0) and bit for bit against the oracle's twins, sums included"""
+    from aivc_amd import ops
+    from aivc_amd.func_util.math_func import PROBA_MAX, PROBA_MIN
+    from aivc_amd.layers.entropy_coding.entropy_coder import EntropyCoder
+    from aivc_amd.layers.entropy_coding.pdf_estimator import BallePdfEstim, ParametricPdf
+    g = golden('rate_est_0')
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).to(cuda)
+    y, mu, sigma, xz = t('y'), t('mu'), t('sigma'), t('xz')
+    pp = ParametricPdf('laplace')
+    with torch.no_grad():
+        p_mu = pp(y, [{'mu': mu, 'sigma': sigma}])
+        p_zero = pp(y, [{'mu': mu, 'sigma': sigma}], zero_mu=True)
+        pe = _load(BallePdfEstim(xz.shape[1], 'balle', verbose=False), g, cuda)
+        p_z = pe(xz)
+        ec = EntropyCoder()
+        rate_y, rate_z = ec(p_zero, y), ec(p_z, xz)
+    np.testing.assert_allclose(p_mu.cpu().numpy(), g['p_mu'], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(p_zero.cpu().numpy(), g['p_zero'], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(p_z.cpu().numpy(), g['p_z'], rtol=0, atol=6e-7)
+    big = g['p_zero'] > 2.0 ** -10
+    np.testing.assert_allclose(rate_y.cpu().numpy()[big], g['rate_y'][big], rtol=0, atol=2e-3)
+    big = g['p_z'] > 2.0 ** -10
+    np.testing.assert_allclose(rate_z.cpu().numpy()[big], g['rate_z'][big], rtol=0, atol=2e-3)
+    # HIP == oracle, bit for bit
+    assert np.array_equal(p_mu.cpu().numpy(), oracle.laplace_prob(g['y'], g['mu'], g['sigma']))
+    assert np.array_equal(p_zero.cpu().numpy(), oracle.laplace_prob(g['y'], None, g['sigma']))
+    _, cdf = pe.cdf_table(cuda, want_float=True)
+    assert np.array_equal(p_z.cpu().numpy(), oracle.table_prob(g['xz'], cdf.cpu().numpy()))
+    r_h, s_h = ops.rate_bits(p_zero, PROBA_MIN, PROBA_MAX)
+    r_o, s_o = oracle.rate_bits(p_zero.cpu().numpy(), PROBA_MIN, PROBA_MAX)
+    assert np.array_equal(r_h.cpu().numpy(), r_o) and float(s_h.cpu()) == s_o
+    # values that are not codable symbols
+    bad = torch.tensor([[[[0.5, 300.0, -257.0, 2.0]]]], device=cuda).expand(1, xz.shape[1], 1, 4).contiguous()
+    out = pe(bad).cpu().numpy()
+    assert np.isnan(out[..., :3]).all() and np.isfinite(out[..., 3]).all()
+
+
+def test_bounds_rate_hip_equals_oracle(cuda, oracle):
+    from aivc_amd import ops
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 1000, 16384, 16385, 200001):
+        lo = rng.integers(0, 0xFFFF, n)
+        hi = lo + 1 + (rng.integers(0, 0x10000, n) % (0x10000 - lo))
+        b = (lo | ((hi & 0xFFFF) << 16)).astype(np.uint32)
+        got = ops.bounds_rate(torch.from_numpy(b.view(np.int32)).to(cuda))
+        assert float(got.cpu()) == oracle.bounds_rate(b), n

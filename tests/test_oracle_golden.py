@@ -237,3 +237,51 @@ def test_laplace_tail_entries_equal_row_entries(oracle):
                                   24.7487, 2.0 ** -10])]).astype(np.float32)
     bad, first = oracle.laplace_tail_mismatches(s)
     assert bad == 0, (bad, first, float(s[first[0]]))
+
+
+def test_rate_estimation_against_the_reference(oracle, golden):
+    """ParametricPdf.forward / BallePdfEstim.forward / EntropyCoder.forward and flag_debug's bit count as the reference
+    computes them (tools/gen_golden.py, rate_est_0) against the oracle's twins of csrc/rate.hip; the probabilities of a
+    factorised-prior symbol are differences of two CDF points in [0, 1]: absolute tolerance of a few fp32 ulps of 1"""
+    from aivc_amd.func_util.math_func import PROBA_MAX, PROBA_MIN
+    from aivc_amd.layers.entropy_coding.pdf_estimator import BallePdfEstim
+    g = golden('rate_est_0')
+    p_mu = oracle.laplace_prob(g['y'], g['mu'], g['sigma'])
+    p_zero = oracle.laplace_prob(g['y'], None, g['sigma'])
+    np.testing.assert_allclose(p_mu, g['p_mu'], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(p_zero, g['p_zero'], rtol=0, atol=3e-7)
+    pe = load_sd(BallePdfEstim(g['xz'].shape[1], 'balle', verbose=False), g)
+    _, cdf = oracle.balle_cdf_table(ospec.export_balle(pe))
+    p_z = oracle.table_prob(g['xz'], cdf)
+    np.testing.assert_allclose(p_z, g['p_z'], rtol=0, atol=6e-7)
+    # -log2 amplifies the absolute error of a small probability: compare the rates where the reference's own fp32
+    # probability carries at least 2^-10 (an error of 6e-7 there moves -log2 by < 1e-3), all of them through the sum
+    for p_ref, r_ref, p_mine in ((g['p_zero'], g['rate_y'], p_zero), (g['p_z'], g['rate_z'], p_z)):
+        rate, total = oracle.rate_bits(p_mine, PROBA_MIN, PROBA_MAX)
+        big = p_ref > 2.0 ** -10
+        np.testing.assert_allclose(rate[big], r_ref[big], rtol=0, atol=2e-3)
+        rate_of_ref, total_of_ref = oracle.rate_bits(p_ref, PROBA_MIN, PROBA_MAX)  # the -log2 alone, same inputs
+        np.testing.assert_allclose(rate_of_ref, r_ref, rtol=2e-6, atol=2e-6)
+        assert abs(total_of_ref - float(r_ref.astype(np.float64).sum())) < 1e-3
+        assert abs(total - float(rate.astype(np.float64).sum())) < 1e-6
+    # flag_debug's figure (clamp at 2^-16): the reference's against the oracle's on the reference's probabilities
+    _, dbg = oracle.rate_bits(g['p_zero'], 2.0 ** -16, 1.0)
+    assert abs(dbg - float(g['dbg_bits_y'])) < 2e-2 * max(1.0, abs(dbg) * 1e-3)
+
+
+def test_bounds_rate_is_the_coded_length(oracle):
+    """sum of -log2((c_hi - c_lo) / 2^16) over the packed bounds: within a few bytes of what the range coder writes
+    (its overhead is < 2 bits + the flush), exactly 0 for certain symbols, the documented reading of c_hi = 0"""
+    rng = np.random.default_rng(3)
+    sig = np.clip(np.exp(rng.uniform(np.log(0.1), np.log(30.0), (1, 40, 50, 3))), 1e-4, 148.4).astype(np.float32)
+    q = np.clip(np.rint(rng.laplace(0, 1, sig.shape) * sig / np.sqrt(2)), -256, 255).astype(np.int16)
+    bounds = oracle.laplace_bounds(sig, q, [0, 1, 2])
+    bits = oracle.bounds_rate(bounds)
+    lo, hi = (bounds & 0xFFFF).astype(np.float64), (bounds >> 16).astype(np.float64)
+    hi[hi == 0] = 65536.0
+    assert abs(bits - float(-np.log2((hi - lo) / 65536.0).sum())) < 1e-6 * bits
+    coded = len(oracle.range_encode(bounds))
+    assert 0 <= coded - bits / 8 < 8, (coded, bits / 8)
+    assert oracle.bounds_rate(np.zeros(0, np.uint32)) == 0.0
+    assert oracle.bounds_rate(np.array([0], np.uint32)) == 0.0  # [0, 2^16): a certain symbol costs nothing
+    assert oracle.bounds_rate(np.array([(0x8000 << 16) | 0], np.uint32)) == 1.0

@@ -296,6 +296,36 @@ def main():
             with torch.no_grad():
                 y = m(torch.from_numpy(x))
         save('wide_' + name, y=y, sha256=np.array(sha), cfg=np.array(repr(dict(build=build, kw=kw, in_shape=in_shape, seed=seed))))
+    # ---- rate estimation (logging): EntropyCoder / ParametricPdf / BallePdfEstim forward and the flag_debug figure ----
+    from layers.entropy_coding.entropy_coder import EntropyCoder
+    from layers.entropy_coding.pdf_estimator import ParametricPdf
+    g2 = torch.Generator().manual_seed(4242)
+    torch.manual_seed(4242)  # (BallePdfEstim draws from the global generator; nothing after this point uses it)
+    c, h, w = 5, 6, 7
+    sigma = torch.exp(torch.rand(1, c, h, w, generator=g2) * 9.0 - 5.0).clamp(1e-4, 148.0)
+    mu = torch.randn(1, c, h, w, generator=g2) * 2.0
+    y = torch.round(torch.randn(1, c, h, w, generator=g2) * sigma * 1.5 + mu).clamp(-256, 256)
+    y[0, 0, 0, :4] = torch.tensor([0., 256., -256., 3.])
+    with torch.no_grad():
+        pp = ParametricPdf('laplace')
+        p_mu = pp(y, [{'mu': mu, 'sigma': sigma}])
+        p_zero = pp(y, [{'mu': mu, 'sigma': sigma}], zero_mu=True)
+        pe = BallePdfEstim(c, 'balle', verbose=False)
+        for p in pe.parameters():
+            p.mul_(1.5)
+        xz = torch.round(torch.randn(1, c, h, w, generator=g2) * 6.0).clamp(-256, 256)
+        xz[0, 1, 0, :3] = torch.tensor([256., -256., 0.])
+        p_z = pe(xz)
+        cdf_z = ArithmeticCoder({'balle_pdf_estim_z': pe, 'device': 'cpu'}).pre_computed_z_cdf.detach().reshape(c, 514)
+        ec = EntropyCoder()
+        rate_y, rate_z = ec(p_zero, y), ec(p_z, xz)
+        # the figure flag_debug prints (src/real_life/bitstream.py:307-318), before the division by 8000
+        b = sigma / torch.sqrt(torch.tensor([2.0]))
+        lap = torch.distributions.Laplace(torch.zeros_like(b), b)
+        dbg_y = -torch.log2(torch.clamp(lap.cdf(y + 0.5) - lap.cdf(y - 0.5), 2 ** -16, 1.)).sum()
+        dbg_z = -torch.log2(torch.clamp(pe(xz), 2 ** -16, 1.)).sum()
+    save('rate_est_0', y=y, mu=mu, sigma=sigma, p_mu=p_mu, p_zero=p_zero, xz=xz, p_z=p_z, cdf_z=cdf_z, rate_y=rate_y,
+         rate_z=rate_z, dbg_bits_y=dbg_y, dbg_bits_z=dbg_z, **sd_np(pe))
     print('done')
 
 
