@@ -266,3 +266,46 @@ def test_fused_tail_layer_in_the_mode(cuda):
     d = (ahead.double() - want.double()).abs().max().item() / want.double().pow(2).mean().sqrt().item()
     print('\nfused tail: bf16x3 vs fp32 contract, max |d| / rms = %.2e' % d)
     assert d < 2e-5
+
+
+@pytest.mark.parametrize('case', ['decoder_mid_gop8', 'decoder_big_gop8', 'decoder_ra', 'decoder_b_mid_gop8'])
+def test_reference_run_decoder_fixtures_in_bf16x3(case, cuda, golden, monkeypatch):
+    """The reference-run decoder fixtures (tests/test_decoder_golden.py: `.bin` files written by the reference's own
+    ArithmeticCoder.encode / container writers, decoded by its decode_one_video to PNG planes) decoded by the HIP path
+    IN THE MODE: planes within +-1 LSB of the reference's, inside the pixel budget of the fp32 contract's test, every
+    section's bit count clean.  decoder_mid_gop8 is the mid-width model (c_in % 32 == 0 on every layer behind the image
+    layers): its wide conv / transposed conv layers must actually TAKE the mode (variant >= 1000), otherwise the test
+    proves nothing about it; the small-width cases run the fp32 contract unchanged (the mode covers no shape of theirs)
+    and must still pass with the switch on."""
+    import test_decoder_golden as tdg
+    from aivc_amd import ops
+    g = golden(case)
+    m = tdg._meta(g)
+    model = tdg._model(golden, case, cuda)
+    tdg._teach_sigma(model, g, m, monkeypatch)
+    fc = model.frame_codec()
+    prev = ops.set_precision('bf16x3')
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            dec, data_dim, first, last = fc.decode_video(np.asarray(g['video_file']).tobytes(), cuda)
+        torch.cuda.synchronize()
+        taken = sorted({p[0] for p in ops.PROFILE if p[0] >= 1000})
+        n_mode = sum(1 for p in ops.PROFILE if p[0] >= 1000)
+        n_all = len(ops.PROFILE)
+    finally:
+        ops.PROFILE = None
+        ops.set_precision(prev)
+    want = tdg._frames(g, m, 'dec')
+    n_off = 0
+    for d, w in zip(dec, want):
+        for k in 'yuv':
+            diff = np.abs(d[k][0].cpu().numpy().astype(np.int32) - w[k].astype(np.int32))
+            assert diff.max() <= 1, (case, k)
+            n_off += int((diff != 0).sum())
+    print('\n%s in bf16x3: %d of %d conv launches in the mode (variants %s), %d samples off by 1 LSB (budget %d)'
+          % (case, n_mode, n_all, taken, n_off, tdg._pixel_budget(m, want)))
+    assert n_off <= tdg._pixel_budget(m, want)
+    assert fc.stream_errors() == []
+    if case == 'decoder_mid_gop8':
+        assert n_mode > 0, 'the mid-width decoder ran no launch in the precision mode'
