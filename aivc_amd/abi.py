@@ -6,8 +6,8 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 15
-PREC_FP32, PREC_BF16X3 = 0, 1  # aivc_conv_params.precision
+ABI_VERSION = 16
+PREC_FP32, PREC_BF16X3, PREC_FP32_WINO = 0, 1, 2  # aivc_conv_params.precision
 
 AIVC_OK = 0
 ERR_UNSUPPORTED = -2
@@ -44,7 +44,7 @@ class ConvParams(C.Structure):
                 ('x', _f), ('w', _f), ('bias', _f), ('mul', _f), ('res', _f), ('y', _f),
                 ('gdn_beta', _f), ('gdn_gamma', _f),
                 ('tail_w', _f), ('tail_bias', _f), ('tail_c_out', C.c_int32), ('precision', C.c_int32),
-                ('w_bf16x3', C.c_void_p)]
+                ('w_bf16x3', C.c_void_p), ('w_wino', _f)]
 
 
 MAX_IMAGES = 3
@@ -104,6 +104,7 @@ PROTOTYPES = {
     'aivc_conv2d': [_P(ConvParams)],
     'aivc_gdn_reparam': [_f, _f, _i32, _fl, _fl, _fl, _f, _f],
     'aivc_split_weights_bf16x3': [_f, _i32, _i32, C.c_void_p],
+    'aivc_winograd_weights': [_f, _i32, _i32, _f],
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],

@@ -49,7 +49,7 @@ static int validate_conv(const aivc_conv_params *p) {
     if (p->gdn < 0 || p->gdn > 2 || p->mode == AIVC_MODE_GDN || p->mode == AIVC_MODE_IGDN) return AIVC_ERR_ARG;
     if (!p->gdn_beta || !p->gdn_gamma) return AIVC_ERR_ARG;
   }
-  if (p->precision != AIVC_PREC_FP32 && p->precision != AIVC_PREC_BF16X3) return AIVC_ERR_ARG;
+  if (p->precision != AIVC_PREC_FP32 && p->precision != AIVC_PREC_BF16X3 && p->precision != AIVC_PREC_FP32_WINO) return AIVC_ERR_ARG;
   if (p->tail_c_out) {
     if (p->tail_c_out < 0 || !p->tail_w || p->mode != AIVC_MODE_CONV || p->gdn || p->mul) return AIVC_ERR_ARG;
   }
@@ -59,6 +59,9 @@ static int validate_conv(const aivc_conv_params *p) {
 AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
+  // version 2 of the contract: the layers it covers run the Winograd chain or nothing (a fused gdn is two launches there)
+  if (p->precision == AIVC_PREC_FP32_WINO && aivc_winograd_covers(p))
+    return aivc::conv2d_wino_supported(*p) ? aivc::conv2d_wino_variant(*p) : AIVC_ERR_UNSUPPORTED;
   if (p->gdn && (p->algo == AIVC_ALGO_DIRECT || !aivc::conv2d_mfma_supported(*p))) return AIVC_ERR_UNSUPPORTED;
   // 1000 + the fp32 code with the mode's tile: the precision mode takes this launch
   if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
@@ -79,6 +82,11 @@ AIVC_EXPORT int aivc_split_weights_bf16x3(const float *w, int32_t c_out, int32_t
   return aivc::split_weights_bf16x3(w, c_out, k_total, out, aivc::to_stream(stream));
 }
 
+AIVC_EXPORT int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream) {
+  if (!w || !u || c_out <= 0 || c_in <= 0) return AIVC_ERR_ARG;
+  return aivc::winograd_weights(w, c_out, c_in, u, aivc::to_stream(stream));
+}
+
 AIVC_EXPORT int aivc_conv_images(const aivc_image_src *src, int32_t n_img, const aivc_conv_params *p, aivc_stream_t stream) {
   if (!p || !p->w || !p->y || !src || n_img < 1 || n_img > AIVC_MAX_IMAGES) return AIVC_ERR_ARG;
   if (p->n <= 0 || p->h_in <= 0 || p->w_in <= 0) return AIVC_ERR_ARG;
@@ -97,6 +105,12 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   int rc = validate_conv(p);
   if (rc != AIVC_OK) return rc;
   hipStream_t s = aivc::to_stream(stream);
+  // version 2 of the fp32 contract: a covered layer is computed by the Winograd chain or not at all (never silently by
+  // the tap chain: the two differ in the last bits and an encoder / decoder pair must agree)
+  if (p->precision == AIVC_PREC_FP32_WINO && aivc_winograd_covers(p)) {
+    if (!p->w_wino) return AIVC_ERR_ARG;
+    return aivc::conv2d_wino(*p, s);
+  }
   // precision mode (never the default): the shapes it covers; everything else runs the fp32 contract
   if (p->precision == AIVC_PREC_BF16X3 && p->algo != AIVC_ALGO_DIRECT && aivc::conv2d_bf16x3_supported(*p) &&
       aivc::conv2d_mfma_supported(*p) && (!p->tail_c_out || aivc::conv2d_mfma_tail_supported(*p)))

@@ -131,6 +131,10 @@ bool conv2d_bf16x3_supported(const aivc_conv_params &p);  // conv_bf16x3.hip: th
 int conv2d_bf16x3(const aivc_conv_params &p, hipStream_t s);
 int split_weights_bf16x3(const float *w, int c_out, int k_total, void *out, hipStream_t s);
 int conv2d_bf16x3_tile(const aivc_conv_params &p);  // tile id of the mode's launch (aivc_conv2d_variant)  // 100 + 10*mode + tile id (+50 fused gdn); 190 fused 1x1 tail
+bool conv2d_wino_supported(const aivc_conv_params &p);  // conv_wino.hip: AIVC_PREC_FP32_WINO, what the kernel can address (no fused gdn)
+int conv2d_wino(const aivc_conv_params &p, hipStream_t s);
+int conv2d_wino_variant(const aivc_conv_params &p);  // 305: 64 tiles x 128 channels, 301: 64 x 64
+int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t s);
 bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p);
 int conv_images(const aivc_image_src *src, int n_img, const aivc_conv_params &p, hipStream_t s);  // conv_images.hip
 bool conv2d_thin_supported(const aivc_conv_params &p);

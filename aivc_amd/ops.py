@@ -105,9 +105,12 @@ def set_precision(mode):
     'bf16x3': the precision MODE of the wide convolutions (include/aivc_hip.h, aivc_conv_params.precision): fp32 operands
     as three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation.  Results are within fp32
     summation-order noise of the contract's, not its bits: an encoder and a decoder must run the same mode.
+    'fp32w': version 2 of the fp32 contract (AIVC_PREC_FP32_WINO): the stride-1 3x3 layers with c_in % 32 == 0 and
+    c_out % 64 == 0 accumulate along Winograd F(2x2, 3x3) chains (16 instead of 36 multiplications per 2x2 outputs);
+    everything else as 'fp32'.  HIP == CPU oracle bit for bit in this version too; its bits are not version 1's.
     -> the previous mode's name.  Process-wide (the codec's side streams read it too)."""
     global PRECISION
-    names = {'fp32': abi.PREC_FP32, 'bf16x3': abi.PREC_BF16X3}
+    names = {'fp32': abi.PREC_FP32, 'bf16x3': abi.PREC_BF16X3, 'fp32w': abi.PREC_FP32_WINO}
     if mode not in names:
         raise ValueError('precision %r: expected one of %s' % (mode, sorted(names)))
     prev = [k for k, v in names.items() if v == PRECISION][0]
@@ -136,6 +139,33 @@ def split_weights_bf16x3(w_ohwi):
     torch.cuda.synchronize(w_ohwi.device)
     _SPLIT_WEIGHTS[key] = (weakref.ref(w_ohwi, lambda _r, k=key: _SPLIT_WEIGHTS.pop(k, None)), stamp, out)
     return out
+
+
+_WINO_WEIGHTS = {}  # id(weight tensor) -> (weak reference, (data_ptr, version), U)
+
+
+def winograd_weights(w_ohwi):
+    """aivc_winograd_weights of an OHWI 3x3 weight ([co, 3, 3, ci] -> U [co, 16, ci]), once per tensor and version
+    (aivc_conv_params.w_wino); closed with a device-wide wait like every other kernel-ready parameter."""
+    import weakref
+    key = id(w_ohwi)
+    stamp = (w_ohwi.data_ptr(), w_ohwi._version)
+    hit = _WINO_WEIGHTS.get(key)
+    if hit is not None and hit[0]() is w_ohwi and hit[1] == stamp:
+        return hit[2]
+    co, k, _, ci = w_ohwi.shape
+    out = torch.empty((co, 16, ci), dtype=torch.float32, device=w_ohwi.device)
+    torch.cuda.synchronize(w_ohwi.device)
+    call('aivc_winograd_weights', _p(w_ohwi), co, ci, _p(out), _stream())
+    torch.cuda.synchronize(w_ohwi.device)
+    _WINO_WEIGHTS[key] = (weakref.ref(w_ohwi, lambda _r, k_=key: _WINO_WEIGHTS.pop(k_, None)), stamp, out)
+    return out
+
+
+def _winograd_covers(mode, k, stride, pad, c, co, act1, act2, tail=False):
+    """include/aivc_hip.h: aivc_winograd_covers"""
+    return mode == abi.MODE_CONV and k == 3 and stride == 1 and pad == 1 and c % 32 == 0 and co % 64 == 0 and not tail \
+        and act1 != 3 and act2 != 3
 
 
 PRESPLIT_WEIGHTS = True  # bf16x3 mode: hand the kernels the split weights (False: they split in their K loop; same bits)
@@ -202,6 +232,8 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
         from ._lib import load
         if load()['aivc_conv2d_variant'](C.byref(p)) >= 1000:  # a launch the mode covers
             p.w_bf16x3 = _p(split_weights_bf16x3(w_ohwi))
+    if PRECISION == abi.PREC_FP32_WINO and _winograd_covers(mode, k, stride, pad, c, co, act1, act2):
+        p.w_wino = _p(winograd_weights(w_ohwi if w_ohwi.is_contiguous() else w_ohwi.contiguous()))
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
         return y

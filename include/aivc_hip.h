@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 15
+#define AIVC_ABI_VERSION 16
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -127,9 +127,32 @@ typedef struct aivc_conv_params {
                          * wrote (c_out * ksize * ksize * c_in * 6 bytes).  Same results bit for bit as with NULL (the
                          * kernels then split the weight fragments in their K loop, ~25 % slower): the terms are the same,
                          * they are only computed once per layer instead of once per tile. */
+  const float *w_wino; /* ABI 16, read under AIVC_PREC_FP32_WINO only (required there for the layers aivc_winograd_covers()
+                        * names): the image of `w` that aivc_winograd_weights wrote, [c_out][16][c_in] floats. */
 } aivc_conv_params;
 #define AIVC_PREC_FP32 0
 #define AIVC_PREC_BF16X3 1
+/* AIVC_PREC_FP32_WINO (ABI 16): the fp32 arithmetic contract, version 2.  Identical to AIVC_PREC_FP32 everywhere except
+ * for the stride-1 3x3 convolutions with replicate padding 1, c_in % 32 == 0 and c_out % 64 == 0 (aivc_winograd_covers;
+ * src/layers/misc/custom_conv_layers.py:21-180, src/layers/misc/attention.py:22-97 build their residual blocks from
+ * them), whose accumulator is the Winograd F(2x2, 3x3) chain below instead of the 9-tap chain: 16 multiplications per
+ * 2x2 output pixels, input channel and output channel instead of 36 (the fp32 matrix pipe is the scarce unit of the
+ * part).  STILL a fixed-order fp32 chain, bit identical on every kernel and on the CPU oracle; within summation-order
+ * noise of version 1 (the per-position chains are 9x shorter), NOT its bits: an encoder and a decoder must run the same
+ * version.  For the output tile (ty, tx) = pixels (2 ty + a, 2 tx + b), a, b in {0, 1}:
+ *   d[r][c]      = x[clamp(2 ty - 1 + r)][clamp(2 tx - 1 + c)],  r, c = 0..3                     (replicate padding)
+ *   position p = 4 i + j, i, j = 0..3, with (A, B, S)[0..3] = (0, 2, -1), (1, 2, +1), (2, 1, -1), (1, 3, -1):
+ *   V_p[ci]      = fmaf(S[i], fmaf(S[j], d[B[i]][B[j]], d[B[i]][A[j]]), fmaf(S[j], d[A[i]][B[j]], d[A[i]][A[j]]))
+ *   M_p[co]      = fmaf chain from +0 over ci (groups of 8 in AIVC_K_ORDER) of V_p[ci] * U[co][p][ci]
+ *   acc[a][b]    = sum over p = 0..15 in ascending order, from +0, of T[a][i] * T[b][j] * M_p  (terms with a zero
+ *                  coefficient are skipped; the others are one fp32 addition or subtraction each),
+ *                  T[0] = (1, 1, 1, 0), T[1] = (0, 1, -1, -1)
+ * then the epilogue of the contract unchanged (bias, fused gdn, act1, mul, res, act2).  U = aivc_winograd_weights(w). */
+#define AIVC_PREC_FP32_WINO 2
+static inline int aivc_winograd_covers(const aivc_conv_params *p) {
+  return p->mode == AIVC_MODE_CONV && p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0 &&
+         p->c_out % 64 == 0 && p->tail_c_out == 0 && p->act1 != AIVC_ACT_SIGMOID && p->act2 != AIVC_ACT_SIGMOID;
+}
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
  *                     s_i = fmaf chain over j (in AIVC_K_ORDER) of (t_j, gamma[i][j]) from +0, then + beta[i];
@@ -140,6 +163,12 @@ typedef struct aivc_conv_params {
  * workgroup tile: c_out of 64 or 128 on the MFMA path; tail: c_out 64 -> tail_c_out 128, c_in % 32 == 0) returns
  * AIVC_ERR_UNSUPPORTED; callers then issue the two launches (aivc_conv2d_variant tells in advance). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
+
+/* AIVC_PREC_FP32_WINO: U[co][4 i + j][ci] = (G g G^T)[i][j] of the 3x3 kernel g[ky][kx] = w[co][ky][kx][ci], G = (1, 0, 0), (.5, .5, .5),
+ * (.5, -.5, .5), (0, 0, 1), evaluated in fp64 in the order  t[i][l] = g[0][l] | .5 * ((g[0][l] + g[1][l]) + g[2][l]) |
+ * .5 * ((g[0][l] - g[1][l]) + g[2][l]) | g[2][l],  then the same along l, rounded once to fp32.  w is OHWI [c_out][3][3][c_in],
+ * u [c_out][16][c_in]. */
+int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
 
 /* AIVC_PREC_BF16X3, weights split ahead of the launches (aivc_conv_params.w_bf16x3): every weight of w [c_out][k_total]
  * (k_total = ksize * ksize * c_in, a multiple of 32: the OHWI rows of aivc_conv2d) as its three bf16 terms

@@ -90,6 +90,29 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
     return np.ascontiguousarray(w)
 
 
+PRECISION = abi.PREC_FP32  # version of the fp32 contract the conv family computes in (set_precision)
+
+
+def set_precision(mode):
+    """'fp32' (version 1: the tap chain) / 'fp32w' (version 2, AIVC_PREC_FP32_WINO: Winograd F(2x2, 3x3) chains for the
+    stride-1 3x3 layers with c_in % 32 == 0, c_out % 64 == 0); -> the previous mode's name.  The bf16x3 mode has no CPU twin."""
+    global PRECISION
+    names = {'fp32': abi.PREC_FP32, 'fp32w': abi.PREC_FP32_WINO}
+    prev = [k for k, v in names.items() if v == PRECISION][0]
+    PRECISION = names[mode]
+    return prev
+
+
+def winograd_weights(w_ohwi):
+    """[co, 3, 3, ci] -> [co, 16, ci] (include/aivc_hip.h: aivc_winograd_weights)"""
+    w_ohwi = _f32(w_ohwi)
+    co, k, _, ci = w_ohwi.shape
+    assert k == 3
+    u = np.empty((co, 16, ci), np.float32)
+    _chk(lib()['aivc_winograd_weights'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights')
+    return u
+
+
 def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, act2=0, mul=None,
            res=None, gdn=None, cmap=None, tail=None):
     """gdn = (beta_eff, gamma_eff, inverse): (inverse) GDN fused after the bias.
@@ -132,7 +155,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     if gdn is not None:
         gb, gg, gflag = _f32(gdn[0]), _f32(gdn[1]), (2 if gdn[2] else 1)
     p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0, gflag, 0,
-                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg), _p(w3), _p(b3), co2, 0)
+                       _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg), _p(w3), _p(b3), co2, PRECISION)
     _chk(lib()['aivc_conv2d'](C.byref(p), None), 'aivc_conv2d')
     return y
 

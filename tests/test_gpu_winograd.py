@@ -1,0 +1,141 @@
+"""Version 2 of the fp32 arithmetic contract (AIVC_PREC_FP32_WINO, include/aivc_hip.h): the stride-1 3x3 layers with
+c_in % 32 == 0 and c_out % 64 == 0 on Winograd F(2x2, 3x3) chains (csrc/conv_wino.hip).  Checked here:
+  * HIP == CPU oracle BIT FOR BIT (the oracle walks the same chain: oracle/aivc_oracle.c) on odd sizes, batches, every
+    epilogue combination, both tile widths; the weight transform likewise;
+  * the error against an fp64 evaluation next to version 1's (both are fp32 summation noise);
+  * layers the version does not cover are version 1's bits unchanged."""
+import numpy as np
+import pytest
+import torch
+
+from aivc_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+CASES = [  # n, h, w, c_in, c_out, act1, act2, bias, mul, res
+    (1, 8, 8, 32, 64, 0, 0, True, False, False),
+    (2, 7, 9, 32, 64, 1, 0, True, False, False),       # odd sizes: half-filled last tile row / column
+    (3, 13, 21, 64, 128, 0, 2, True, False, True),     # residual + relu
+    (1, 17, 30, 128, 128, 1, 0, True, False, True),    # leaky then residual (ChengResBlock)
+    (5, 5, 3, 128, 64, 0, 1, False, True, True),       # no bias, gate multiplicand, tiny images: a tile spans images
+    (1, 1, 1, 32, 64, 0, 0, True, False, False),       # a single pixel
+    (2, 34, 60, 128, 128, 0, 0, True, False, False),
+    (1, 9, 40, 64, 192, 2, 0, True, False, False),     # c_out 192: three 64-channel tiles
+    (1, 68, 120, 128, 128, 0, 0, True, False, True),   # the 1/16-resolution shape of 1080p
+]
+
+
+def _inputs(case, seed):
+    n, h, w, ci, co, a1, a2, has_b, has_m, has_r = case
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
+    wt = (rng.standard_normal((co, 3, 3, ci)) / np.sqrt(9 * ci)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32) if has_b else None
+    m = rng.standard_normal((n, h, w, co)).astype(np.float32) if has_m else None
+    r = rng.standard_normal((n, h, w, co)).astype(np.float32) if has_r else None
+    return x, wt, b, m, r
+
+
+@pytest.fixture()
+def fp32w(oracle):
+    from aivc_amd import ops
+    prev_h, prev_o = ops.set_precision('fp32w'), oracle.set_precision('fp32w')
+    yield
+    ops.set_precision(prev_h)
+    oracle.set_precision(prev_o)
+
+
+@pytest.mark.parametrize('idx', range(len(CASES)))
+def test_hip_equals_oracle_bit_for_bit(idx, cuda, oracle, fp32w):
+    from aivc_amd import ops
+    case = CASES[idx]
+    n, h, w, ci, co, a1, a2, _, _, _ = case
+    x, wt, b, m, r = _inputs(case, 100 + idx)
+    want = oracle.conv2d(x, wt, b, stride=1, pad=1, act1=a1, act2=a2, mul=m, res=r)
+    dv = lambda a: None if a is None else T(a, cuda)
+    ops.PROFILE = []
+    try:
+        got = ops.conv2d(dv(x), dv(wt), dv(b), stride=1, pad=1, act1=a1, act2=a2, mul=dv(m), res=dv(r))
+        torch.cuda.synchronize()
+        variants = [pr[0] for pr in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert variants == [305 if co % 128 == 0 else 301], variants
+    assert np.array_equal(got.cpu().numpy(), want), (case, float(np.abs(got.cpu().numpy() - want).max()))
+
+
+def test_weight_transform_equals_oracle(cuda, oracle):
+    from aivc_amd import ops
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal((64, 3, 3, 96)) * 3).astype(np.float32)
+    u = ops.winograd_weights(T(w, cuda)).cpu().numpy()
+    assert np.array_equal(u, oracle.winograd_weights(w))
+    # G g G^T in fp64
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    ref = np.einsum('ik,oklc,jl->oijc', G, w.astype(np.float64), G).reshape(64, 16, 96)
+    assert np.abs(u - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+
+
+def test_error_against_fp64_next_to_version_1(cuda, oracle):
+    """the two versions of the contract against an fp64 evaluation of a 3x3 128 -> 128 layer: both are summation noise of an
+    fp32 accumulator; version 2's per-position chains are 9 times shorter"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((1, 40, 52, 128)).astype(np.float32) * 3
+    wt = (rng.standard_normal((128, 3, 3, 128)) / np.sqrt(9 * 128)).astype(np.float32)
+    b = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (1, 1, 1, 1), mode='replicate'),
+                                     torch.from_numpy(wt).double().permute(0, 3, 1, 2), torch.from_numpy(b).double())
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    errs = {}
+    for mode in ('fp32', 'fp32w'):
+        prev = ops.set_precision(mode)
+        try:
+            y = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=1, pad=1).cpu().numpy()
+        finally:
+            ops.set_precision(prev)
+        e = np.abs(y - ref) / np.maximum(1.0, np.abs(ref))
+        errs[mode] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
+    print('\nmax / rms error vs fp64: version 1 %.2e / %.2e, version 2 (Winograd) %.2e / %.2e' % (errs['fp32'] + errs['fp32w']))
+    assert errs['fp32w'][0] <= max(2e-5, 4 * errs['fp32'][0]) and errs['fp32w'][1] <= 3 * errs['fp32'][1]
+
+
+def test_uncovered_layers_keep_version_1_bits(cuda, fp32w):
+    """stride 2, 5x5, 1x1, c_in not a multiple of 32, transposed: version 2 is version 1 there"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(12)
+    for mode, k, s, pad, ci, co in ((abi.MODE_CONV, 3, 2, 1, 64, 64), (abi.MODE_CONV, 5, 1, 2, 32, 64), (abi.MODE_CONV, 1, 1, 0, 64, 64),
+                                    (abi.MODE_CONV, 3, 1, 1, 16, 64), (abi.MODE_TCONV, 3, 2, 0, 64, 64), (abi.MODE_CONV, 3, 1, 1, 64, 32)):
+        x = T(rng.standard_normal((1, 10, 12, ci)).astype(np.float32), cuda)
+        w = T((rng.standard_normal((co, k, k, ci)) / np.sqrt(k * k * ci)).astype(np.float32), cuda)
+        y2 = ops.conv2d(x, w, None, mode=mode, stride=s, pad=pad)
+        prev = ops.set_precision('fp32')
+        try:
+            y1 = ops.conv2d(x, w, None, mode=mode, stride=s, pad=pad)
+        finally:
+            ops.set_precision(prev)
+        assert torch.equal(y1, y2), (mode, k, s, ci, co)
+
+
+def test_fused_gdn_request_is_two_launches_with_the_oracle_bits(cuda, oracle, fp32w):
+    """a covered layer with a fused (I)GDN: the Winograd launch then the GDN-mode launch (aivc_conv2d_variant says the
+    fusion is not available in this version) == the oracle's fused evaluation"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(21)
+    c = 128
+    x = rng.standard_normal((2, 11, 9, c)).astype(np.float32)
+    wt = (rng.standard_normal((c, 3, 3, c)) / np.sqrt(9 * c)).astype(np.float32)
+    b = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    beta = (1.0 + rng.uniform(0, .5, c)).astype(np.float32)
+    gamma = (0.1 * np.eye(c) + rng.uniform(0, .05, (c, c))).astype(np.float32)
+    res = rng.standard_normal((2, 11, 9, c)).astype(np.float32)
+    for inverse in (False, True):
+        want = oracle.conv2d(x, wt, b, stride=1, pad=1, gdn=(beta, gamma, inverse), res=res)
+        got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=1, pad=1, gdn=(T(beta, cuda), T(gamma, cuda), inverse), res=T(res, cuda))
+        assert np.array_equal(got.cpu().numpy(), want), inverse
