@@ -26,6 +26,7 @@ BALLE_PARAMS = 43
 MAX_MAPS = 256
 RC_MAX_STREAMS = 64
 RATE_LANES = 16384
+WINO_MIN_PIXELS = 16384  # include/aivc_hip.h: AIVC_WINO_MIN_PIXELS
 
 FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 
@@ -33,6 +34,7 @@ _f = C.c_void_p  # every buffer pointer travels as an integer address
 
 
 CONV_SPARSE4 = 1  # aivc_conv_params.flags: every 4th stored input channel is zero (images padded 3 -> 4)
+CONV_WINO_ANY_SIZE = 2  # ... version 2 of the fp32 contract whatever the image size (tests)
 
 
 class ConvParams(C.Structure):

@@ -83,7 +83,7 @@ AIVC_EXPORT int aivc_split_weights_bf16x3(const float *w, int32_t c_out, int32_t
 }
 
 AIVC_EXPORT int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream) {
-  if (!w || !u || c_out <= 0 || c_in <= 0) return AIVC_ERR_ARG;
+  if (!w || !u || c_out <= 0 || c_in <= 0 || c_out % 64 || c_in % 8) return AIVC_ERR_ARG;
   return aivc::winograd_weights(w, c_out, c_in, u, aivc::to_stream(stream));
 }
 

@@ -4,24 +4,25 @@
 //   why            the fp32 matrix pipe is the scarce unit of this part (157 TFLOP/s, 1/16 of the bf16 rate) and the codec's
 //                  step is 0.75 of it end to end: what is left under the tap chain is ~10 %.  F(2x2, 3x3) issues 16
 //                  multiplications per 2x2 output pixels and channel pair instead of 36.
-//   GEMM view      M = output TILES (n, ty, tx) of 2x2 pixels, N = output channels, K = (position p = 0..15, ci): sixteen
-//                  GEMMs of reduction length c_in that share one accumulator tile in turn -- after the last K-tile of a
-//                  position the accumulators M_p are folded into the four output accumulators (a, b) with coefficients
-//                  0 / +-1 and cleared.  Each M_p is the fixed-order fmaf chain of v_mfma_f32_32x32x2_f32 over ci in
-//                  AIVC_K_ORDER; the fold adds the positions in ascending order: one fixed chain per output, the CPU oracle
-//                  (oracle/aivc_oracle.c) walks the same one.
-//   A operand      V_p = the input transform of the 4x4 patch, never in memory: the four input pixels a position combines
-//                  (rows A[i] / B[i], columns A[j] / B[j] of the patch, replicate-clamped) go global -> LDS by LDS-DMA into
-//                  four raw planes of [64 tiles][32 channels]; the workgroup turns them into the A tile in place of a
-//                  ds_write pass of a register-staged loader: 4 ds_read_b128 + 12 v_fma + 1 ds_write_b128 per float4 of V.
-//   B operand      U = G g G^T, transformed once per layer (aivc_winograd_weights, fp64, rounded once), [c_out][16][c_in]: a
-//                  K-contiguous row per output channel like the OHWI weights of the tap kernels, fetched by the same
-//                  LDS-DMA into a two-stage ring.
-//   LDS image      rows of 128 bytes (32 channels), XOR-swizzled 16-byte slots exactly as in conv_mfma.hip (slot s of row R
-//                  holds data chunk s ^ (R & 7) ^ ((R >> 3) & 3)); raw planes and A tile share the layout, so the transform
-//                  is slot-wise.  32 KB raw + 8 KB A + 2 x 16 KB B = 72 KB: two workgroups per CU.
-//   schedule       per K-tile: [DMA of this tile landed] barrier, transform raw -> A, barrier, issue the DMAs of the next
-//                  tile (raw planes are free, the other B stage was read a tile ago), 32 MFMAs per wave.
+//   first version  (round 6, experiments/r06.md): position-outer K loop, the four input pixels of a position fetched per
+//                  position and K-tile -- 12 KB of L2 -> LDS traffic per output pixel at 2.25x the tap kernel's pace
+//                  (~11 TB/s asked of the L2): 0.56 of the matrix peak, 1.2x the tap kernel.  This version fetches every
+//                  input pixel of a block ONCE per channel chunk.
+//   work split     a workgroup = a block of 8 x 8 output tiles (16 x 16 pixels) x 64 output channels, 8 waves: (4 x 8 tiles)
+//                  x 32 channels x 8 of the 16 positions each -- 8 accumulator blocks (128 registers) per wave, two waves per
+//                  SIMD.  The reduction runs over chunks of 8 input channels (one octet of AIVC_K_ORDER = four
+//                  v_mfma_f32_32x32x2_f32 steps per position); M_p = a fixed-order fmaf chain over ci per position, as the
+//                  contract says.  After the last chunk a wave folds its 8 positions into the partial sums S0 / S1 of the
+//                  four outputs of every tile, the two waves of a pair exchange halves through LDS and each finishes one
+//                  output row (a = 0 / a = 1) of the tiles.
+//   per chunk      raw patch (18 x 18 pixels x 8 channels, 10 KB: replicate-clamped on the global side of the LDS-DMA, stored
+//                  as four parity planes so that the transform's reads are contiguous), U image (16 positions x 64 channels x
+//                  8, 32 KB: aivc_winograd_weights lays it out as it is staged, one contiguous copy), V (16 positions x 64
+//                  tiles x 8, by a cooperative transform: 8 ds_read_b128 + 32 v_fma + 4 ds_write_b128 per thread).
+//                  Everything double-buffered (158 KB of LDS, one workgroup per CU) and ONE barrier per chunk: in chunk c a
+//                  wave issues the DMAs of raw(c + 2) and U(c + 1), transforms raw(c + 1) into the other V buffer and
+//                  multiplies chunk c -- the two waves of a SIMD in opposite order, so that one's transform runs under the
+//                  other's MFMAs.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -35,245 +36,406 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct WinoArgs {
   aivc_conv_params p;
-  int M;                // output tiles: n * TH * TW
-  int TH, TW;           // tiles per image column / row
-  uint32_t tw_magic, th_magic, img_magic;  // floor(2^32 / TW), floor(2^32 / TH), floor(2^32 / (TH * TW)): quotients low by at most one
-  int gy;               // c_out tiles
+  int TH, TW;    // output tiles per image column / row
+  int nby, nbx;  // blocks of 8 x 8 tiles per image
+  int gy;        // blocks of 64 output channels
+  int total;     // blocks in all: n * nby * nbx * gy
 };
 
 __device__ __forceinline__ void wino_glds16(const float *base, uint32_t voff, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
-__device__ __forceinline__ uint32_t udiv_magic(uint32_t v, uint32_t magic, uint32_t d) {  // v / d for d >= 1 (magic = floor(2^32 / d); d = 1: magic saturates)
-  if (d == 1u) return v;
-  uint32_t q = __umulhi(v, magic);
-  if (v - q * d >= d) ++q;
-  return q;
-}
+constexpr int WINO_RAW_STAGE = 11 * 1024;  // 648 slots of 16 bytes (4 parity planes x 81 pixels x 2 channel quads), 11 DMA instructions
+constexpr int WINO_U_STAGE = 32 * 1024;    // [16 positions][2 quads][64 channels][4 floats]
+constexpr int WINO_V_QUAD = 1152;          // [64 tiles][4 floats] + 128: the second quad starts 32 banks further
+constexpr int WINO_V_POS = 2 * WINO_V_QUAD;
+constexpr int WINO_V_STAGE = 16 * WINO_V_POS;
+constexpr int WINO_LDS = 2 * (WINO_RAW_STAGE + WINO_U_STAGE + WINO_V_STAGE);
 
-// TN: 32-channel accumulator blocks per wave along N; the workgroup tile is 64 tiles x (64 TN) output channels, waves 2 x 2
-template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
-  constexpr int BM = 64, BN = 64 * TN, ROWB = 128;
-  constexpr int PLANE = BM * ROWB, RAW_B = 4 * PLANE, A_B = BM * ROWB, BSTAGE = BN * ROWB;
-  constexpr int GB = BN / 32;  // B DMA instructions per wave and K-tile
+__global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wsmem[];
-  char *raw = wsmem, *As = wsmem + RAW_B, *Bs = As + A_B;
+  char *raw = wsmem, *Us = wsmem + 2 * WINO_RAW_STAGE, *Vs = Us + 2 * WINO_U_STAGE;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)wsmem;
 
   const aivc_conv_params &p = a.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int H = p.h_in, W = p.w_in, Cin = p.c_in, Cout = p.c_out, M = a.M, TH = a.TH, TW = a.TW;
+  const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;  // waves w and w + 4 (one SIMD) = the two position halves of a sub-tile
+  const int H = p.h_in, W = p.w_in, Cin = p.c_in, Cout = p.c_out;
 
-  // XCD-aware tile order (as conv_mfma.hip): one XCD works on a contiguous run of tiles
-  uint32_t tile_id;
-  {
-    const uint32_t nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int by = (int)(tile_id % (uint32_t)a.gy), bx = (int)(tile_id / (uint32_t)a.gy);
-  const int m0 = bx * BM, n0 = by * BN;
-
-  // every per-lane input offset is relative to the image of the tile's first row (32-bit byte offsets: a tile of 64 output
-  // tiles spans few images; the host checks the span)
-  const uint32_t img0 = udiv_magic((uint32_t)m0, a.img_magic, (uint32_t)(TH * TW));
-  const float *xbase = p.x + (size_t)img0 * (size_t)H * W * Cin;
-
-  const int l3 = lane >> 3;
-  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ l3 ^ wave) << 4);  // this lane's data chunk (bytes) in a K row
-  // the lane's two raw rows (rows 8 wave + l3 and + 32 of the tile)
-  int g_y0[2], g_x0[2];
-  uint32_t g_nb[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    int m = m0 + 8 * wave + 32 * g + l3;
-    m = m < M ? m : M - 1;
-    const uint32_t t = udiv_magic((uint32_t)m, a.tw_magic, (uint32_t)TW), tx = (uint32_t)m - t * (uint32_t)TW;
-    const uint32_t n = udiv_magic(t, a.th_magic, (uint32_t)TH), ty = t - n * (uint32_t)TH;
-    g_y0[g] = 2 * (int)ty - 1;
-    g_x0[g] = 2 * (int)tx - 1;
-    g_nb[g] = (n - img0) * (uint32_t)(H * W);
-  }
-  uint32_t g_avo[2][4], g_bvo[GB];
-#pragma unroll
-  for (int j = 0; j < GB; ++j) {
-    const int co = n0 + 32 * j + 8 * wave + l3;  // (c_out % 64 == 0: every row exists)
-    g_bvo[j] = (uint32_t)co * (uint32_t)(16 * Cin * 4) + chunk_b;
-  }
-  const uint32_t adst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
-  const uint32_t bdst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(RAW_B + A_B) + (uint32_t)wave * 1024u);
-
-  // state of the NEXT tile to issue
-  int nx_pos = 0, nx_c = 0;
-  const float *urun = p.w_wino;
-  auto set_position = [&](int pos) {  // per-lane byte offsets of the four input pixels position `pos` combines
-    const int i = pos >> 2, j = pos & 3;
-    const int ai = i == 0 ? 0 : (i == 2 ? 2 : 1), bi = i == 3 ? 3 : (i == 2 ? 1 : 2);
-    const int aj = j == 0 ? 0 : (j == 2 ? 2 : 1), bj = j == 3 ? 3 : (j == 2 ? 1 : 2);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int ra = max(min(g_y0[g] + ai, H - 1), 0), rb = max(min(g_y0[g] + bi, H - 1), 0);
-      const int ca = max(min(g_x0[g] + aj, W - 1), 0), cb = max(min(g_x0[g] + bj, W - 1), 0);
-      const uint32_t c4 = (uint32_t)(Cin * 4);
-      g_avo[g][0] = (g_nb[g] + (uint32_t)(ra * W + ca)) * c4 + chunk_b;
-      g_avo[g][1] = (g_nb[g] + (uint32_t)(ra * W + cb)) * c4 + chunk_b;
-      g_avo[g][2] = (g_nb[g] + (uint32_t)(rb * W + ca)) * c4 + chunk_b;
-      g_avo[g][3] = (g_nb[g] + (uint32_t)(rb * W + cb)) * c4 + chunk_b;
-    }
+  // Persistent workgroups (one per CU: a.nwg of them) walk the blocks.  The dispatcher deals consecutive workgroup ids
+  // round-robin to the 8 XCDs (each with a private L2): workgroup b sits on XCD b & 7 and takes blocks of that XCD's
+  // contiguous eighth of the block list, interleaved with the other workgroups of the XCD -- they advance through one region
+  // together; the channel blocks of a pixel block are neighbours in the list (same raw patch).
+  const uint32_t total = (uint32_t)a.total, nwg = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t per_xcd = (total + 7u) >> 3, wg_per_xcd = (nwg + 7u - xcd) >> 3;  // workgroups on this XCD
+  const uint32_t x_lo = xcd * per_xcd, x_hi = min(x_lo + per_xcd, total);
+  auto block_of = [&](uint32_t k) -> uint32_t { return x_lo + slot + k * wg_per_xcd; };  // k-th block of this workgroup
+  const uint32_t n_mine = x_lo + slot < x_hi ? (x_hi - x_lo - slot + wg_per_xcd - 1u) / wg_per_xcd : 0u;
+  if (n_mine == 0u) return;
+  // descriptor of a block: what the loader needs (image base, chunk images of its channel block, per-lane patch offsets) and
+  // what the epilogue needs (coordinates)
+  struct Desc {
+    const float *xbase, *ubase;
+    uint32_t r_off[2];
+    int img, byi, bxi, cb;
   };
-  auto issue_tile = [&](int stage) {
-    if (nx_c == 0) set_position(nx_pos);
-    const float *ab = xbase + nx_c;
+  // raw: instruction k of 11 writes slots 64 k .. 64 k + 63; wave w issues k = w and, for w < 3, k = w + 8.  slot = (plane *
+  // 81 + hy * 9 + hx) * 2 + quad with plane = (py & 1) * 2 + (px & 1), hy = py >> 1, hx = px >> 1 for patch pixel (py, px)
+  int s_quad[2], s_py[2], s_px[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+  for (int k = 0; k < 2; ++k) {
+    int sl = 64 * (wave + 8 * k) + lane;
+    sl = sl < 648 ? sl : 647;  // (pad lanes of the last instruction fetch the last slot again)
+    const int q2 = sl >> 1, plane = q2 / 81, rem = q2 - plane * 81, hy = rem / 9, hx = rem - hy * 9;
+    s_quad[k] = sl & 1;
+    s_py[k] = 2 * hy + (plane >> 1);
+    s_px[k] = 2 * hx + (plane & 1);
+  }
+  auto make_desc = [&](uint32_t blk) {
+    Desc d;
+    d.cb = (int)(blk % (uint32_t)a.gy);
+    uint32_t rest = blk / (uint32_t)a.gy;
+    d.bxi = (int)(rest % (uint32_t)a.nbx);
+    rest /= (uint32_t)a.nbx;
+    d.byi = (int)(rest % (uint32_t)a.nby);
+    d.img = (int)(rest / (uint32_t)a.nby);
+    d.xbase = p.x + (size_t)d.img * (size_t)H * W * Cin;                         // this image (32-bit byte offsets inside it)
+    d.ubase = p.w_wino + (size_t)d.cb * (size_t)(Cin / 8) * (WINO_U_STAGE / 4);  // this channel block's chunk images
 #pragma unroll
-      for (int g = 0; g < 2; ++g) wino_glds16(ab, g_avo[g][t], adst + (uint32_t)(t * PLANE + g * 4096));
-    const uint32_t bd = bdst + (uint32_t)stage * BSTAGE;
-#pragma unroll
-    for (int j = 0; j < GB; ++j) wino_glds16(urun, g_bvo[j], bd + j * 4096);
-    urun += 32;
-    nx_c += 32;
-    if (nx_c == Cin) {
-      nx_c = 0;
-      ++nx_pos;
+    for (int k = 0; k < 2; ++k) {
+      const int iy = max(min(16 * d.byi - 1 + s_py[k], H - 1), 0), ix = max(min(16 * d.bxi - 1 + s_px[k], W - 1), 0);
+      d.r_off[k] = ((uint32_t)(iy * W + ix) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
     }
+    return d;
+  };
+  Desc cur = make_desc(block_of(0)), nxt = n_mine > 1u ? make_desc(block_of(1)) : cur;
+
+  const uint32_t r_dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+  const uint32_t u_dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(2 * WINO_RAW_STAGE) + (uint32_t)wave * 4096u);
+  const uint32_t u_off = (uint32_t)(wave * 4096 + lane * 16);
+  const int nch = Cin >> 3;
+  auto issue_raw = [&](const Desc &d_, int c) {  // chunk c of block d_ -> raw stage c & 1
+    const float *src = d_.xbase + 8 * c;
+    const uint32_t *r_off = d_.r_off;
+    const uint32_t d = r_dst + (uint32_t)((c & 1) * WINO_RAW_STAGE);
+    wino_glds16(src, r_off[0], d);
+    if (wave < 3) wino_glds16(src, r_off[1], d + 8192u);
+  };
+  auto issue_u = [&](const Desc &d_, int c) {  // chunk c of block d_ -> U stage c & 1: a straight copy of the chunk image
+    const float *src = d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
+    const uint32_t d = u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wino_glds16(src, u_off + (uint32_t)(j * 1024), d + (uint32_t)(j * 1024));
   };
 
-  floatx16 acc[TN], yacc[4][TN];
+  // ---- transform plan: thread = (tile, channel quad, row i of the 4 x 4 positions) -----------------------------------------
+  const int t_quad = tid & 1, t_tx = (tid >> 1) & 7, t_ty = (tid >> 4) & 7;
+  const int t_i = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int t_ra = t_i == 0 ? 0 : (t_i == 2 ? 2 : 1), t_rb = t_i == 3 ? 3 : (t_i == 2 ? 1 : 2);  // rows A[i], B[i] of the patch
+  const float t_si = t_i == 1 ? 1.0f : -1.0f;
+  const int t_base = ((t_ty * 9 + t_tx) * 2 + t_quad) * 16;
+  // byte offset of patch pixel (2 ty + r, 2 tx + c) relative to t_base
+  auto pix_off = [](int r, int c) { return (((r & 1) * 2 + (c & 1)) * 81 + (r >> 1) * 9 + (c >> 1)) * 32; };
+  int t_oa[4], t_ob[4];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc[j][r] = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) yacc[q][j][r] = 0.0f;
-    }
-
-  // fragment reads: lane reads row (lane & 31) of its 32-row blocks, data chunk 2 o + (lane >> 5)
-  const int sw = (lane & 7) ^ ((lane >> 3) & 3);
-  const char *a_rd = As + (wm * 32 + (lane & 31)) * ROWB;
-  const char *b_rd = Bs + (wn * TN * 32 + (lane & 31)) * ROWB;
-  int f_off[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o) f_off[o] = ((2 * o + (lane >> 5)) ^ sw) << 4;
-
-  const int kc = Cin >> 5, nkt = 16 * kc;
-  int cur_pos = 0, cur_c = 0;  // position of the tile being multiplied, K-tiles of it done
-  issue_tile(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // this tile's raw planes and B stage are in LDS; everybody is done with the A tile
-    {
-      // V = (x_aa + s_j x_ab) + s_i (x_ba + s_j x_bb), slot-wise on the swizzled image
-      const int i = cur_pos >> 2, j = cur_pos & 3;
-      const float si = i == 1 ? 1.0f : -1.0f, sj = j == 1 ? 1.0f : -1.0f;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int off = (tid + 256 * u) * 16;
-        const float4 xaa = *reinterpret_cast<const float4 *>(raw + off), xab = *reinterpret_cast<const float4 *>(raw + PLANE + off);
-        const float4 xba = *reinterpret_cast<const float4 *>(raw + 2 * PLANE + off), xbb = *reinterpret_cast<const float4 *>(raw + 3 * PLANE + off);
-        float4 v;
-        v.x = __builtin_fmaf(si, __builtin_fmaf(sj, xbb.x, xba.x), __builtin_fmaf(sj, xab.x, xaa.x));
-        v.y = __builtin_fmaf(si, __builtin_fmaf(sj, xbb.y, xba.y), __builtin_fmaf(sj, xab.y, xaa.y));
-        v.z = __builtin_fmaf(si, __builtin_fmaf(sj, xbb.z, xba.z), __builtin_fmaf(sj, xab.z, xaa.z));
-        v.w = __builtin_fmaf(si, __builtin_fmaf(sj, xbb.w, xba.w), __builtin_fmaf(sj, xab.w, xaa.w));
-        *reinterpret_cast<float4 *>(As + off) = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // the A tile is complete, the raw planes are free
-    if (kt + 1 < nkt) issue_tile((kt + 1) & 1);
-    {
-      const int sb = (kt & 1) * BSTAGE;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        const float4 af = *reinterpret_cast<const float4 *>(a_rd + f_off[o]);
-        float4 bf[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b_rd + sb + j * 32 * ROWB + f_off[o]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float av = s == 0 ? af.x : (s == 1 ? af.y : (s == 2 ? af.z : af.w));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float bv = s == 0 ? bf[j].x : (s == 1 ? bf[j].y : (s == 2 ? bf[j].z : bf[j].w));
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (++cur_c == kc) {
-      // fold M_p into the four outputs of the tile: coefficient T[a][i] * T[b][j], T[0] = (1, 1, 1, 0), T[1] = (0, 1, -1, -1)
-      const int i = cur_pos >> 2, j = cur_pos & 3;
-      const int t0i = i < 3 ? 1 : 0, t1i = i == 0 ? 0 : (i == 1 ? 1 : -1);
-      const int t0j = j < 3 ? 1 : 0, t1j = j == 0 ? 0 : (j == 1 ? 1 : -1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cf = ((q >> 1) ? t1i : t0i) * ((q & 1) ? t1j : t0j);  // wave-uniform
-        if (cf > 0) {
-#pragma unroll
-          for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) yacc[q][jj][r] = yacc[q][jj][r] + acc[jj][r];
-        } else if (cf < 0) {
-#pragma unroll
-          for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) yacc[q][jj][r] = yacc[q][jj][r] - acc[jj][r];
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.0f;
-      cur_c = 0;
-      ++cur_pos;
-    }
+  for (int c = 0; c < 4; ++c) {
+    t_oa[c] = t_base + pix_off(t_ra, c);
+    t_ob[c] = t_base + pix_off(t_rb, c);
   }
+  const int t_vdst = (4 * t_i) * WINO_V_POS + t_quad * WINO_V_QUAD + (t_ty * 8 + t_tx) * 16;
+  // the transform of one chunk in 8 steps (interleaved with the 8 positions of the multiply): steps 0-3 combine the rows of
+  // patch column cc = step (R[cc] = d[A_i][cc] + S_i d[B_i][cc]), steps 4-7 write V_j = R[A_j] + S_j R[B_j], j = step - 4
+  float4 R[4];
+  auto comb = [](const float4 &u, const float4 &v, float sgn) {
+    float4 o;
+    o.x = __builtin_fmaf(sgn, v.x, u.x);
+    o.y = __builtin_fmaf(sgn, v.y, u.y);
+    o.z = __builtin_fmaf(sgn, v.z, u.z);
+    o.w = __builtin_fmaf(sgn, v.w, u.w);
+    return o;
+  };
+  auto transform_step = [&](int c, auto STEP) {  // raw stage c & 1 -> V stage c & 1
+    constexpr int st = decltype(STEP)::value;
+    const char *rs = raw + (c & 1) * WINO_RAW_STAGE;
+    char *vd = Vs + (c & 1) * WINO_V_STAGE + t_vdst;
+    if constexpr (st < 4) {
+      const float4 xa = *reinterpret_cast<const float4 *>(rs + t_oa[st]), xb = *reinterpret_cast<const float4 *>(rs + t_ob[st]);
+      R[st] = comb(xa, xb, t_si);
+    } else if constexpr (st == 4) {
+      *reinterpret_cast<float4 *>(vd) = comb(R[0], R[2], -1.0f);
+    } else if constexpr (st == 5) {
+      *reinterpret_cast<float4 *>(vd + WINO_V_POS) = comb(R[1], R[2], 1.0f);
+    } else if constexpr (st == 6) {
+      *reinterpret_cast<float4 *>(vd + 2 * WINO_V_POS) = comb(R[2], R[1], -1.0f);
+    } else {
+      *reinterpret_cast<float4 *>(vd + 3 * WINO_V_POS) = comb(R[1], R[3], -1.0f);
+    }
+  };
+  auto transform = [&](int c) {
+    using std::integral_constant;
+    transform_step(c, integral_constant<int, 0>{});
+    transform_step(c, integral_constant<int, 1>{});
+    transform_step(c, integral_constant<int, 2>{});
+    transform_step(c, integral_constant<int, 3>{});
+    transform_step(c, integral_constant<int, 4>{});
+    transform_step(c, integral_constant<int, 5>{});
+    transform_step(c, integral_constant<int, 6>{});
+    transform_step(c, integral_constant<int, 7>{});
+  };
 
-  // ---- epilogue: the contract's order (Epilogue::finish, common.h) on the four outputs of every tile --------------------
-  const float *__restrict__ g_mul = p.mul;
-  const float *__restrict__ g_res = p.res;
-  float *__restrict__ g_y = p.y;
+  // ---- multiply plan -------------------------------------------------------------------------------------------------------
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int a_rd = (8 * ph) * WINO_V_POS + hh * WINO_V_QUAD + (32 * wm + l31) * 16;
+  const int b_rd = (8 * ph) * 2048 + hh * 1024 + (32 * wn + l31) * 16;
+  // chunk c multiplied (8 positions x 4 MFMAs) with the transform of chunk c + 1 dealt out between the positions: one
+  // instruction stream per wave in which matrix and vector / LDS work alternate, so that the two waves of a SIMD fill each
+  // other's gaps without any phase arrangement
+  auto multiply = [&](int c, bool with_transform) {
+    const char *va = Vs + (c & 1) * WINO_V_STAGE + a_rd, *ub = Us + (c & 1) * WINO_U_STAGE + b_rd;
+    // positions in pairs: the MFMAs of two accumulators alternate (a dependent MFMA waits for its predecessor's last pass),
+    // the fragments of the next pair are read while this pair multiplies, the transform steps follow the pair's MFMAs (the
+    // first MFMAs behind the chunk's barrier then wait for two LDS round trips only)
+    float4 af[2][2], bf[2][2];
+    auto rd = [&](int set, int q) {
+      af[set][0] = *reinterpret_cast<const float4 *>(va + q * WINO_V_POS);
+      bf[set][0] = *reinterpret_cast<const float4 *>(ub + q * 2048);
+      af[set][1] = *reinterpret_cast<const float4 *>(va + (q + 1) * WINO_V_POS);
+      bf[set][1] = *reinterpret_cast<const float4 *>(ub + (q + 1) * 2048);
+    };
+    rd(0, 0);
+    auto pair = [&](auto Q) {
+      constexpr int q = decltype(Q)::value, set = (q >> 1) & 1;
+      using std::integral_constant;
+      if constexpr (q + 2 < 8) rd(1 - set, q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 x0 = af[set][0], y0 = bf[set][0], x1 = af[set][1], y1 = bf[set][1];
+#ifdef WINO_EXP_NOMFMA
+      acc[q][0] += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
+      acc[q + 1][0] += x1.x * y1.x + x1.y * y1.y + x1.z * y1.z + x1.w * y1.w;
+#else
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, acc[q], 0, 0, 0);
+      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, acc[q + 1], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
+      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
+      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
+      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_EXP_NOXFORM
+      if (with_transform) {
+        transform_step(c + 1, integral_constant<int, q>{});
+        transform_step(c + 1, integral_constant<int, q + 1>{});
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using std::integral_constant;
+    pair(integral_constant<int, 0>{});
+    pair(integral_constant<int, 2>{});
+    pair(integral_constant<int, 4>{});
+    pair(integral_constant<int, 6>{});
+  };
+
+  // ---- the reduction, pipelined ACROSS blocks: chunk indices run on through the workgroup's blocks (c_in / 8 is even, so
+  // the stage parity of a chunk is its index inside its block) -------------------------------------------------------------
+  auto issue_raw_at = [&](uint32_t kb, int c) {  // chunk c of this workgroup's block kb, c possibly beyond the block's chunks
+    if (c < nch) issue_raw(cur, c);
+    else if (kb + 1u < n_mine) issue_raw(nxt, c - nch);
+  };
+  auto issue_u_at = [&](uint32_t kb, int c) {
+    if (c < nch) issue_u(cur, c);
+    else if (kb + 1u < n_mine) issue_u(nxt, c - nch);
+  };
+  issue_raw(cur, 0);
+  issue_u(cur, 0);
+  issue_raw_at(0u, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  transform(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   const int act1 = p.act1, act2 = p.act2;
   auto act_cheap = [](int act, float v) {  // NONE / LEAKY / RELU of act_apply() without branches
     const float neg = act == AIVC_ACT_LEAKY ? v * 0.01f : (act == AIVC_ACT_RELU ? 0.0f : v);
     return v > 0.0f ? v : neg;
   };
-  float cb[TN];
-  int cch[TN];
+  for (uint32_t kb = 0; kb < n_mine; ++kb) {
+    for (int c = 0; c < nch; ++c) {
+      // here: V(c) complete, U(c) and raw(c + 1) in LDS; raw stage c & 1, U stage (c + 1) & 1 and V stage (c + 1) & 1 are free
+      // (chunks beyond this block's are the first ones of the next block)
+#ifndef WINO_EXP_NODMA
+      issue_raw_at(kb, c + 2);
+      issue_u_at(kb, c + 1);
+#endif
+      multiply(c, c + 1 < nch || kb + 1u < n_mine);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- fold: S[a][b] = sum over this wave's positions (ascending, from +0) of T[a][i] T[b][j] M_p ------------------------------
+    floatx16 S[4];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    cch[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
-    cb[j] = p.bias ? p.bias[cch[j]] : 0.0f;
-  }
-  const bool has_bias = p.bias != nullptr;
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m >= M) continue;
-    const uint32_t t = udiv_magic((uint32_t)m, a.tw_magic, (uint32_t)TW), tx = (uint32_t)m - t * (uint32_t)TW;
-    const uint32_t n = udiv_magic(t, a.th_magic, (uint32_t)TH), ty = t - n * (uint32_t)TH;
+      for (int r = 0; r < 16; ++r) S[o][r] = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oy = 2 * (int)ty + (q >> 1), ox = 2 * (int)tx + (q & 1);
-      if (oy >= H || ox >= W) continue;  // (odd sizes: the last tile row / column holds one pixel row / column)
-      const size_t base = (((size_t)n * H + oy) * W + ox) * (size_t)Cout;
+    for (int q = 0; q < 8; ++q) {
+      const int i = 2 * ph + (q >> 2), j = q & 3;  // (i: wave-uniform at run time, j: compile time)
+      const int t0i = i < 3 ? 1 : 0, t1i = i == 0 ? 0 : (i == 1 ? 1 : -1);
+      const int t0j = j < 3 ? 1 : 0, t1j = j == 0 ? 0 : (j == 1 ? 1 : -1);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const size_t o = base + cch[j];
-        float v = yacc[q][j][r];
-        if (has_bias) v = v + cb[j];
-        v = act_cheap(act1, v);
-        if (g_mul) v = g_mul[o] * v;
-        if (g_res) v = v + g_res[o];
-        v = act_cheap(act2, v);
-        g_y[o] = v;
+      for (int o = 0; o < 4; ++o) {
+        const int cf = ((o >> 1) ? t1i : t0i) * ((o & 1) ? t1j : t0j);
+        if (cf > 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[o][r] = S[o][r] + acc[q][r];
+        } else if (cf < 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[o][r] = S[o][r] - acc[q][r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    }
+    // exchange: the wave of half ph finishes output row a = ph of the tiles; it hands its partial sums of the other row to its
+    // partner (wave ^ 4), one output column b at a time, through the V stage the reduction does not touch before the next
+    // chunk's transform (stage 1: the last chunk's V went to stage (nch - 1) & 1 = 1; the next block's chunk 0 sits in stage 0)
+    {
+      float *xch = reinterpret_cast<float *>(Vs + WINO_V_STAGE) + wave * 1024;  // [16 registers][64 lanes] per wave: 32 KB
+      const float *theirs = reinterpret_cast<const float *>(Vs + WINO_V_STAGE) + (wave ^ 4) * 1024;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = ph ? S[b][r] : S[2 + b][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float other = theirs[r * 64 + lane];
+          // acc[a][b] = S0 + S1 (one fp32 addition: the same bits whichever wave performs it)
+          if (ph) S[2 + b][r] = other + S[2 + b][r];
+          else S[b][r] = S[b][r] + other;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
     }
+
+    // ---- epilogue: the contract's order (Epilogue::finish, common.h) on output row a = ph of every tile -------------------
+    {
+      const float *__restrict__ g_mul = p.mul;
+      const float *__restrict__ g_res = p.res;
+      float *__restrict__ g_y = p.y;
+      const int co = cur.cb * 64 + 32 * wn + l31;
+      const bool has_bias = p.bias != nullptr;
+      const float cbias = has_bias ? p.bias[co] : 0.0f;
+      const int oy_w = 2 * (8 * cur.byi + 4 * wm) + ph;  // output row of the wave's first tile row (wave-uniform)
+      const bool inside_x = 16 * cur.bxi + 16 <= W;
+      if (inside_x && !g_mul && act1 != AIVC_ACT_SIGMOID) {
+        // fast path (every block but the right-edge column): one wave-uniform 64-bit base per tile row, one 32-bit byte
+        // offset per lane, tile column and output column as immediates -- no per-element address arithmetic, no lane masks
+        typedef __attribute__((address_space(1))) char gchar;
+        typedef __attribute__((address_space(1))) float gfloat;
+        typedef __attribute__((address_space(1))) const float cgfloat;
+        const uint32_t c4 = (uint32_t)Cout * 4u;
+        uint32_t lane_b = (uint32_t)(2 * (8 * cur.bxi + 4 * hh)) * c4 + (uint32_t)co * 4u;
+        asm volatile("" : "+v"(lane_b));
+        const size_t img_b = (size_t)cur.img * (size_t)H * W * c4;
+        auto rows = [&](auto RES, auto KIND) {
+          constexpr bool has_res = decltype(RES)::value;
+          constexpr int kind = decltype(KIND)::value;  // act1 / act2 combination, see below
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int oy = oy_w + 2 * rq;
+            if (oy >= H) continue;  // wave-uniform
+            const size_t row_b = img_b + (size_t)oy * W * c4;
+            gchar *yb = (gchar *)(uintptr_t)(reinterpret_cast<char *>(g_y) + row_b);
+            const gchar *rb = (const gchar *)(uintptr_t)(reinterpret_cast<const char *>(g_res) + row_b);
+            float rv[8];
+            if constexpr (has_res) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) rv[rr * 2 + b] = *reinterpret_cast<cgfloat *>(rb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const int r = rq * 4 + rr;
+                float v = ph ? S[2 + b][r] : S[b][r];
+                if (has_bias) v = v + cbias;
+                if constexpr (kind == 1) v = __builtin_fmaxf(v, v * 0.01f);       // act1 leaky (same bits as the select: common.h)
+                if constexpr (kind == 2) v = v > 0.0f ? v : 0.0f;                 // act1 relu
+                if constexpr (has_res) v = v + rv[rr * 2 + b];
+                if constexpr (kind == 3) v = v > 0.0f ? v : 0.0f;                 // act2 relu
+                if constexpr (kind == 4) v = __builtin_fmaxf(v, v * 0.01f);       // act2 leaky
+#ifdef WINO_EXP_NOSTORE
+                if (v == 123.456f)
+#endif
+                *reinterpret_cast<gfloat *>(yb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) = v;
+              }
+          }
+        };
+        using std::integral_constant;
+        // kinds: 0 none; 1 / 2: act1 leaky / relu (act2 none); 3 / 4: act2 relu / leaky (act1 none); anything else -> slow path
+        int kind = -1;
+        if (act1 == AIVC_ACT_NONE && act2 == AIVC_ACT_NONE) kind = 0;
+        else if (act2 == AIVC_ACT_NONE) kind = act1 == AIVC_ACT_LEAKY ? 1 : 2;
+        else if (act1 == AIVC_ACT_NONE) kind = act2 == AIVC_ACT_RELU ? 3 : 4;
+        if (kind >= 0 && Cout % 128 == 0) {
+          auto go = [&](auto RES) {
+            switch (kind) {
+              case 0: rows(RES, integral_constant<int, 0>{}); break;
+              case 1: rows(RES, integral_constant<int, 1>{}); break;
+              case 2: rows(RES, integral_constant<int, 2>{}); break;
+              case 3: rows(RES, integral_constant<int, 3>{}); break;
+              default: rows(RES, integral_constant<int, 4>{}); break;
+            }
+          };
+          if (g_res) go(integral_constant<bool, true>{});
+          else go(integral_constant<bool, false>{});
+          goto epilogue_done;
+        }
+      }
+      {
+        const size_t ybase = (size_t)cur.img * (size_t)H * W * Cout + (size_t)co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;  // tile of the wave's 4 x 8
+          const int oy = oy_w + 2 * (t >> 3), ox0 = 2 * (8 * cur.bxi + (t & 7));
+          if (oy >= H) continue;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int ox = ox0 + b;
+            if (ox >= W) continue;
+            const size_t o = ybase + ((size_t)oy * W + ox) * (size_t)Cout;
+            float v = ph ? S[2 + b][r] : S[b][r];
+            if (has_bias) v = v + cbias;
+            v = act_cheap(act1, v);
+            if (g_mul) v = g_mul[o] * v;
+            if (g_res) v = v + g_res[o];
+            v = act_cheap(act2, v);
+#ifdef WINO_EXP_NOSTORE
+            if (v == 123.456f)
+#endif
+            g_y[o] = v;
+          }
+        }
+      }
+    epilogue_done:;
+    }
+    cur = nxt;
+    if (kb + 2u < n_mine) nxt = make_desc(block_of(kb + 2u));
   }
 }
 
@@ -302,7 +464,7 @@ __global__ void __launch_bounds__(256) winograd_weights_kernel(const float *w, i
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u[((size_t)co * 16 + 4 * i + j) * c_in + ci] = (float)uu[i][j];
+    for (int j = 0; j < 4; ++j) u[AIVC_WINO_U_INDEX(co, 4 * i + j, ci, c_in)] = (float)uu[i][j];
 }
 
 int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t s) {
@@ -310,42 +472,38 @@ int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t 
   return check_launch("winograd_weights");
 }
 
-// what the kernel can address: 32-bit byte offsets relative to the image of a tile's first row
+// what the kernel can address: 32-bit byte offsets inside one image
 bool conv2d_wino_supported(const aivc_conv_params &p) {
   if (!aivc_winograd_covers(&p) || p.gdn) return false;
-  const uint64_t th = (uint64_t)(p.h_in + 1) / 2, tw = (uint64_t)(p.w_in + 1) / 2;
-  const uint64_t img_bytes = (uint64_t)p.h_in * p.w_in * p.c_in * 4u;
-  const uint64_t span_imgs = 64u / (th * tw) + 2u;  // images a tile of 64 output tiles can touch
-  if (img_bytes * span_imgs >= 0xFFFF0000ull) return false;
-  if ((uint64_t)p.n * th * tw >= 0x7FFFFFFFull) return false;
-  if ((uint64_t)p.c_out * 16u * p.c_in * 4u >= 0xFFFF0000ull) return false;
-  return true;
+  if ((uint64_t)p.h_in * p.w_in * p.c_in * 4u >= 0xFFFF0000ull) return false;
+  const uint64_t blocks = (uint64_t)p.n * (((uint64_t)p.h_in + 15) / 16) * (((uint64_t)p.w_in + 15) / 16) * ((uint64_t)p.c_out / 64);
+  return blocks < 0x7FFFFFFFull;
 }
 
-int conv2d_wino_variant(const aivc_conv_params &p) { return p.c_out % 128 == 0 ? 305 : 301; }
+int conv2d_wino_variant(const aivc_conv_params &) { return 301; }
 
-template <int TN>
-static int launch_wino(const aivc_conv_params &p, hipStream_t s) {
+int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
+  if (!conv2d_wino_supported(p) || !p.w_wino) return AIVC_ERR_UNSUPPORTED;
   WinoArgs a;
   a.p = p;
   a.TH = (p.h_in + 1) / 2;
   a.TW = (p.w_in + 1) / 2;
-  a.M = p.n * a.TH * a.TW;
-  a.tw_magic = (uint32_t)(0x100000000ull / (uint64_t)a.TW);
-  a.th_magic = (uint32_t)(0x100000000ull / (uint64_t)a.TH);
-  a.img_magic = (uint32_t)(0x100000000ull / ((uint64_t)a.TH * a.TW));
-  a.gy = p.c_out / (64 * TN);
-  const size_t lds = (size_t)4 * 64 * 128 + 64 * 128 + 2 * (64 * TN) * 128;
+  a.nby = (a.TH + 7) / 8;
+  a.nbx = (a.TW + 7) / 8;
+  a.gy = p.c_out / 64;
   static LdsOptIn opt_in;
-  if (!opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel<TN>), lds)) return check_launch("conv_wino lds attribute");
-  const unsigned grid = (unsigned)(((a.M + 63) / 64) * a.gy);
-  hipLaunchKernelGGL(conv_wino_kernel<TN>, dim3(grid), dim3(256), lds, s, a);
+  if (!opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel), WINO_LDS)) return check_launch("conv_wino lds attribute");
+  a.total = (int)((size_t)p.n * a.nby * a.nbx * a.gy);
+  static std::atomic<int> n_cu{0};
+  if (n_cu.load(std::memory_order_relaxed) == 0) {
+    int dev = 0, cus = 0;
+    n_cu = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 ? cus : 256;
+  }
+  // persistent workgroups, one per CU (158 KB of LDS each); a multiple of 8 so that every XCD gets its share of the list
+  unsigned grid = (unsigned)n_cu.load(std::memory_order_relaxed);
+  if ((unsigned)a.total < grid) grid = (unsigned)a.total;
+  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WINO_LDS, s, a);
   return check_launch("conv_wino");
-}
-
-int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
-  if (!conv2d_wino_supported(p) || !p.w_wino) return AIVC_ERR_UNSUPPORTED;
-  return p.c_out % 128 == 0 ? launch_wino<2>(p, s) : launch_wino<1>(p, s);
 }
 
 }  // namespace aivc

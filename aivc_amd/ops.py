@@ -18,6 +18,7 @@ FRAME_I, FRAME_P, FRAME_B = abi.FRAME_I, abi.FRAME_P, abi.FRAME_B
 
 # when bench.py sets this to a list, every aivc_conv2d launch is bracketed by HIP events
 PROFILE = None
+PROFILE_DIRECT_EQUIVALENT = [0.0, 0.0]  # Winograd launches while PROFILE is on: [tap-chain FLOPs they replace, FLOPs they execute]
 # likewise for the HBM-bound stages: (name, algorithmic bytes, event, event) per launch
 PROFILE_HBM = None
 
@@ -145,7 +146,7 @@ _WINO_WEIGHTS = {}  # id(weight tensor) -> (weak reference, (data_ptr, version),
 
 
 def winograd_weights(w_ohwi):
-    """aivc_winograd_weights of an OHWI 3x3 weight ([co, 3, 3, ci] -> U [co, 16, ci]), once per tensor and version
+    """aivc_winograd_weights of an OHWI 3x3 weight ([co, 3, 3, ci] -> co * 16 * ci floats), once per tensor and version
     (aivc_conv_params.w_wino); closed with a device-wide wait like every other kernel-ready parameter."""
     import weakref
     key = id(w_ohwi)
@@ -154,7 +155,7 @@ def winograd_weights(w_ohwi):
     if hit is not None and hit[0]() is w_ohwi and hit[1] == stamp:
         return hit[2]
     co, k, _, ci = w_ohwi.shape
-    out = torch.empty((co, 16, ci), dtype=torch.float32, device=w_ohwi.device)
+    out = torch.empty(co * 16 * ci, dtype=torch.float32, device=w_ohwi.device)  # (the kernels' staging order, AIVC_WINO_U_INDEX)
     torch.cuda.synchronize(w_ohwi.device)
     call('aivc_winograd_weights', _p(w_ohwi), co, ci, _p(out), _stream())
     torch.cuda.synchronize(w_ohwi.device)
@@ -162,12 +163,13 @@ def winograd_weights(w_ohwi):
     return out
 
 
-def _winograd_covers(mode, k, stride, pad, c, co, act1, act2, tail=False):
+def _winograd_covers(mode, k, stride, pad, c, co, act1, act2, h, w, tail=False):
     """include/aivc_hip.h: aivc_winograd_covers"""
-    return mode == abi.MODE_CONV and k == 3 and stride == 1 and pad == 1 and c % 32 == 0 and co % 64 == 0 and not tail \
-        and act1 != 3 and act2 != 3
+    return mode == abi.MODE_CONV and k == 3 and stride == 1 and pad == 1 and c % 32 == 0 and co % 128 == 0 and not tail \
+        and act1 != 3 and act2 != 3 and (h * w >= abi.WINO_MIN_PIXELS or WINO_ANY_SIZE)
 
 
+WINO_ANY_SIZE = False  # tests: fp32w on images below AIVC_WINO_MIN_PIXELS too (aivc_conv_params.flags, AIVC_CONV_WINO_ANY_SIZE)
 PRESPLIT_WEIGHTS = True  # bf16x3 mode: hand the kernels the split weights (False: they split in their K loop; same bits)
 
 
@@ -214,6 +216,8 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
             raise AivcNativeError('conv2d: %s shape %s != output shape %s' % (nm, tuple(t.shape), tuple(y.shape)))
     # 3-channel images stored as 4: the zero pad channels are exact no-ops the MFMA kernels may skip
     flags = abi.CONV_SPARSE4 if cmap is not None and all(ci % 4 != 3 for ci in cmap) else 0
+    if WINO_ANY_SIZE:
+        flags |= abi.CONV_WINO_ANY_SIZE
     if gdn is not None:
         g_beta, g_gamma, g_inv = gdn
         p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, algo, 2 if g_inv else 1, flags,
@@ -232,7 +236,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
         from ._lib import load
         if load()['aivc_conv2d_variant'](C.byref(p)) >= 1000:  # a launch the mode covers
             p.w_bf16x3 = _p(split_weights_bf16x3(w_ohwi))
-    if PRECISION == abi.PREC_FP32_WINO and _winograd_covers(mode, k, stride, pad, c, co, act1, act2):
+    if PRECISION == abi.PREC_FP32_WINO and _winograd_covers(mode, k, stride, pad, c, co, act1, act2, h, w_):
         p.w_wino = _p(winograd_weights(w_ohwi if w_ohwi.is_contiguous() else w_ohwi.contiguous()))
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
@@ -243,6 +247,12 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     taps = k * k
     pix = n * h * w_ if mode == abi.MODE_TCONV else n * ho * wo
     flops = 2.0 * taps * c_real * co * pix + (2.0 * co * co * n * ho * wo if gdn is not None else 0.0)
+    if variant == 301:
+        # version 2 of the contract: what the matrix pipe EXECUTES (16 multiplications per tile of 2 x 2 outputs and channel
+        # pair instead of 36) -- a roofline fraction is priced on issued work; the tap chain's count is kept beside it
+        PROFILE_DIRECT_EQUIVALENT[0] += flops
+        flops = 2.0 * 16 * c_real * co * n * ((h + 1) // 2) * ((w_ + 1) // 2)
+        PROFILE_DIRECT_EQUIVALENT[1] += flops
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call('aivc_conv2d', C.byref(p), _stream())

@@ -57,6 +57,8 @@ def variant_name(v):
         return 'thin_mfma_kernel'
     if v == 190:
         return 'conv_mfma<conv,128x64+tail1x1>'
+    if v == 301:
+        return 'conv_wino<8x8 tiles,64>'
     if v >= 1000:
         return 'bf16x3:' + variant_name(v - 1000)
     if v == 191:
@@ -118,6 +120,8 @@ def cpu_baseline(width, height, model, fc, dev, gop_name='1_GOP_32', unit_frames
     from oracle import spec as ospec
     from oracle import torch_cpu
     orc.lib()
+    from aivc_amd import abi as _abi, ops as _ops
+    orc.set_precision('fp32w' if _ops.PRECISION == _abi.PREC_FP32_WINO else 'fp32')  # the checker walks the contract version the GPU runs
     cores = os.cpu_count() or 1
     spec = ospec.export_model(model)
     frames = synth.synthetic_video(width, height, 3, seed=11)
@@ -257,6 +261,8 @@ def main():
     ap.add_argument('--lean-encoder-steps', type=int, default=2)
     ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
     ap.add_argument('--precision-steps', type=int, default=2)
+    ap.add_argument('--contract', choices=('fp32', 'fp32w'), default=os.environ.get('AIVC_BENCH_CONTRACT', 'fp32'),
+                    help="version of the fp32 arithmetic contract: 'fp32' = version 1 (tap chains), 'fp32w' = version 2 (Winograd F(2x2,3x3) chains for the stride-1 3x3 layers it covers, include/aivc_hip.h); HIP == CPU oracle bit for bit in both")
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -300,6 +306,7 @@ def main():
 
     from aivc_amd import ops, parallel, synth
     from aivc_amd.func_util.GOP_structure import generate_gop_struct
+    ops.set_precision(args.contract)
     from aivc_amd.models import arch
     widths = arch.TINY_WIDTHS if args.tiny else arch.DEFAULT_WIDTHS
     seed = 1234
@@ -458,6 +465,7 @@ def main():
     if not args.no_roofline and rank == 0:
         ops.PROFILE = []
         ops.PROFILE_HBM = []
+        ops.PROFILE_DIRECT_EQUIVALENT[:] = [0.0, 0.0]
         step(clips[n_total - 1])  # one single-rank step, instrumented
         torch.cuda.synchronize()
         per = {}
@@ -508,7 +516,11 @@ def main():
                         'all_mfma_conv': {'achieved': round(all_fl / all_sec / 1e12, 2),
                                           'frac': round(all_fl / all_sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                           'tflop_per_step': round(all_fl / 1e12, 3),
-                                          'kernel_s_per_step': round(all_sec, 4)},
+                                          'kernel_s_per_step': round(all_sec, 4),
+                                          # version 2 of the contract: the Winograd launches are priced on the FLOPs they execute;
+                                          # this is the tap-chain work of the same layers (version 1 would have issued it)
+                                          'winograd_replaces_tflop_per_step': round(ops.PROFILE_DIRECT_EQUIVALENT[0] / 1e12, 3),
+                                          'winograd_executes_tflop_per_step': round(ops.PROFILE_DIRECT_EQUIVALENT[1] / 1e12, 3)},
                         'per_variant': {VARIANT_NAMES.get(v, str(v)): {'launches': d[0], 'tflops': round(d[1] / d[2] / 1e12, 2),
                                                                        'frac': round(d[1] / d[2] / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                                                        'ms_total': round(d[2] * 1e3, 2)}
@@ -678,7 +690,7 @@ def main():
             'value': round(clips_done * args.frames / elapsed, 4), 'unit': 'frames/s',
             'n_gpus': dist.get_world_size() if use_dist else 1, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True,
-            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'arithmetic_contract': args.contract,
             'config': {'workload': '%dx%d 8-bit YUV420, coding structure %s: one %d-frame clip = %d intra-period units of %d frames '
                                    '(%d coded frames, the last %d repeat the last frame) encoded + decoded per step; synthetic '
                                    'random-init stand-in for model ms_ssim-4 (widths %s), last analysis conv calibrated so that '

@@ -128,12 +128,14 @@ typedef struct aivc_conv_params {
                          * kernels then split the weight fragments in their K loop, ~25 % slower): the terms are the same,
                          * they are only computed once per layer instead of once per tile. */
   const float *w_wino; /* ABI 16, read under AIVC_PREC_FP32_WINO only (required there for the layers aivc_winograd_covers()
-                        * names): the image of `w` that aivc_winograd_weights wrote, [c_out][16][c_in] floats. */
+                        * names): the image of `w` that aivc_winograd_weights wrote, c_out * 16 * c_in floats. */
 } aivc_conv_params;
 #define AIVC_PREC_FP32 0
 #define AIVC_PREC_BF16X3 1
 /* AIVC_PREC_FP32_WINO (ABI 16): the fp32 arithmetic contract, version 2.  Identical to AIVC_PREC_FP32 everywhere except
- * for the stride-1 3x3 convolutions with replicate padding 1, c_in % 32 == 0 and c_out % 64 == 0 (aivc_winograd_covers;
+ * for the stride-1 3x3 convolutions with replicate padding 1, c_in % 32 == 0, c_out % 128 == 0 (not the 64-channel 3x3 of the
+ * bottleneck blocks, which the kernels fuse with its 1x1 tail: fused or in two launches, it stays version 1), no fused 1x1 tail and at
+ * least AIVC_WINO_MIN_PIXELS input pixels per image (aivc_winograd_covers: a function of the layer and its input size only;
  * src/layers/misc/custom_conv_layers.py:21-180, src/layers/misc/attention.py:22-97 build their residual blocks from
  * them), whose accumulator is the Winograd F(2x2, 3x3) chain below instead of the 9-tap chain: 16 multiplications per
  * 2x2 output pixels, input channel and output channel instead of 36 (the fp32 matrix pipe is the scarce unit of the
@@ -142,16 +144,21 @@ typedef struct aivc_conv_params {
  * version.  For the output tile (ty, tx) = pixels (2 ty + a, 2 tx + b), a, b in {0, 1}:
  *   d[r][c]      = x[clamp(2 ty - 1 + r)][clamp(2 tx - 1 + c)],  r, c = 0..3                     (replicate padding)
  *   position p = 4 i + j, i, j = 0..3, with (A, B, S)[0..3] = (0, 2, -1), (1, 2, +1), (2, 1, -1), (1, 3, -1):
- *   V_p[ci]      = fmaf(S[i], fmaf(S[j], d[B[i]][B[j]], d[B[i]][A[j]]), fmaf(S[j], d[A[i]][B[j]], d[A[i]][A[j]]))
- *   M_p[co]      = fmaf chain from +0 over ci (groups of 8 in AIVC_K_ORDER) of V_p[ci] * U[co][p][ci]
- *   acc[a][b]    = sum over p = 0..15 in ascending order, from +0, of T[a][i] * T[b][j] * M_p  (terms with a zero
- *                  coefficient are skipped; the others are one fp32 addition or subtraction each),
- *                  T[0] = (1, 1, 1, 0), T[1] = (0, 1, -1, -1)
+ *   R_i[c][ci]   = fmaf(S[i], d[B[i]][c], d[A[i]][c])                                             (rows first)
+ *   V_p[ci]      = fmaf(S[j], R_i[B[j]], R_i[A[j]])
+ *   M_p[co]      = fmaf chain from +0 over ci (groups of 8 in AIVC_K_ORDER) of V_p[ci] * U_p[co][ci]
+ *   acc[a][b]    = S0 + S1,  S0 = sum over p = 0..7, S1 = sum over p = 8..15, each in ascending order from +0, of
+ *                  T[a][i] * T[b][j] * M_p  (terms with a zero coefficient are skipped; the others are one fp32 addition
+ *                  or subtraction each),  T[0] = (1, 1, 1, 0), T[1] = (0, 1, -1, -1)
  * then the epilogue of the contract unchanged (bias, fused gdn, act1, mul, res, act2).  U = aivc_winograd_weights(w). */
 #define AIVC_PREC_FP32_WINO 2
+#define AIVC_WINO_MIN_PIXELS 16384 /* h_in * w_in from which the version applies: below it the 16 x 16-pixel blocks of the kernel
+                                    * quantise the image badly and a launch is a handful of blocks per CU (68 x 120: no gain) */
+#define AIVC_CONV_WINO_ANY_SIZE 2 /* aivc_conv_params.flags: version 2 whatever the image size (the tests drive the kernel on shapes the oracle checks in seconds) */
 static inline int aivc_winograd_covers(const aivc_conv_params *p) {
   return p->mode == AIVC_MODE_CONV && p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0 &&
-         p->c_out % 64 == 0 && p->tail_c_out == 0 && p->act1 != AIVC_ACT_SIGMOID && p->act2 != AIVC_ACT_SIGMOID;
+         p->c_out % 128 == 0 && p->tail_c_out == 0 && p->act1 != AIVC_ACT_SIGMOID && p->act2 != AIVC_ACT_SIGMOID &&
+         ((int64_t)p->h_in * p->w_in >= AIVC_WINO_MIN_PIXELS || (p->flags & AIVC_CONV_WINO_ANY_SIZE));
 }
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
@@ -164,10 +171,14 @@ static inline int aivc_winograd_covers(const aivc_conv_params *p) {
  * AIVC_ERR_UNSUPPORTED; callers then issue the two launches (aivc_conv2d_variant tells in advance). */
 int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
 
-/* AIVC_PREC_FP32_WINO: U[co][4 i + j][ci] = (G g G^T)[i][j] of the 3x3 kernel g[ky][kx] = w[co][ky][kx][ci], G = (1, 0, 0), (.5, .5, .5),
- * (.5, -.5, .5), (0, 0, 1), evaluated in fp64 in the order  t[i][l] = g[0][l] | .5 * ((g[0][l] + g[1][l]) + g[2][l]) |
- * .5 * ((g[0][l] - g[1][l]) + g[2][l]) | g[2][l],  then the same along l, rounded once to fp32.  w is OHWI [c_out][3][3][c_in],
- * u [c_out][16][c_in]. */
+/* AIVC_PREC_FP32_WINO: U_p[co][ci], p = 4 i + j, = (G g G^T)[i][j] of the 3x3 kernel g[ky][kx] = w[co][ky][kx][ci], G = (1, 0, 0),
+ * (.5, .5, .5), (.5, -.5, .5), (0, 0, 1), evaluated in fp64 in the order  t[i][l] = g[0][l] | .5 * ((g[0][l] + g[1][l]) + g[2][l]) |
+ * .5 * ((g[0][l] - g[1][l]) + g[2][l]) | g[2][l],  then the same along l, rounded once to fp32.  w is OHWI [c_out][3][3][c_in]
+ * (c_in % 8 == 0, c_out % 64 == 0); u is laid out as the kernels stage it, one contiguous 32 KB image per (block of 64 output
+ * channels, chunk of 8 input channels):  u[AIVC_WINO_U_INDEX(co, p, ci, c_in)]. */
+#define AIVC_WINO_U_INDEX(co, p, ci, c_in) \
+  ((((((size_t)((co) / 64) * (size_t)((c_in) / 8) + (size_t)((ci) / 8)) * 16 + (size_t)(p)) * 2 + (size_t)(((ci) % 8) / 4)) * 64 + \
+    (size_t)((co) % 64)) * 4 + (size_t)((ci) % 4))
 int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
 
 /* AIVC_PREC_BF16X3, weights split ahead of the launches (aivc_conv_params.w_bf16x3): every weight of w [c_out][k_total]

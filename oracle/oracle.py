@@ -91,6 +91,7 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
 
 
 PRECISION = abi.PREC_FP32  # version of the fp32 contract the conv family computes in (set_precision)
+WINO_ANY_SIZE = False  # tests: version 2 below AIVC_WINO_MIN_PIXELS too (aivc_conv_params.flags)
 
 
 def set_precision(mode):
@@ -104,11 +105,11 @@ def set_precision(mode):
 
 
 def winograd_weights(w_ohwi):
-    """[co, 3, 3, ci] -> [co, 16, ci] (include/aivc_hip.h: aivc_winograd_weights)"""
+    """[co, 3, 3, ci] -> co * 16 * ci floats in the staging order of include/aivc_hip.h (AIVC_WINO_U_INDEX)"""
     w_ohwi = _f32(w_ohwi)
     co, k, _, ci = w_ohwi.shape
     assert k == 3
-    u = np.empty((co, 16, ci), np.float32)
+    u = np.empty(co * 16 * ci, np.float32)
     _chk(lib()['aivc_winograd_weights'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights')
     return u
 
@@ -154,7 +155,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     gflag = 0
     if gdn is not None:
         gb, gg, gflag = _f32(gdn[0]), _f32(gdn[1]), (2 if gdn[2] else 1)
-    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0, gflag, 0,
+    p = abi.ConvParams(mode, k, stride, pad, n, h, w_, c, ho, wo, co, act1, act2, 0, gflag, abi.CONV_WINO_ANY_SIZE if WINO_ANY_SIZE else 0,
                        _p(x), _p(w_ohwi), _p(bias), _p(mul), _p(res), _p(y), _p(gb), _p(gg), _p(w3), _p(b3), co2, PRECISION)
     _chk(lib()['aivc_conv2d'](C.byref(p), None), 'aivc_conv2d')
     return y

@@ -1,5 +1,5 @@
 """Version 2 of the fp32 arithmetic contract (AIVC_PREC_FP32_WINO, include/aivc_hip.h): the stride-1 3x3 layers with
-c_in % 32 == 0 and c_out % 64 == 0 on Winograd F(2x2, 3x3) chains (csrc/conv_wino.hip).  Checked here:
+c_in % 32 == 0 and c_out % 128 == 0 on Winograd F(2x2, 3x3) chains (csrc/conv_wino.hip).  Checked here:
   * HIP == CPU oracle BIT FOR BIT (the oracle walks the same chain: oracle/aivc_oracle.c) on odd sizes, batches, every
     epilogue combination, both tile widths; the weight transform likewise;
   * the error against an fp64 evaluation next to version 1's (both are fp32 summation noise);
@@ -18,15 +18,18 @@ def T(a, dev):
 
 
 CASES = [  # n, h, w, c_in, c_out, act1, act2, bias, mul, res
-    (1, 8, 8, 32, 64, 0, 0, True, False, False),
-    (2, 7, 9, 32, 64, 1, 0, True, False, False),       # odd sizes: half-filled last tile row / column
+    (1, 8, 8, 32, 128, 0, 0, True, False, False),
+    (2, 7, 9, 32, 128, 1, 0, True, False, False),      # odd sizes: half-filled last tile row / column
     (3, 13, 21, 64, 128, 0, 2, True, False, True),     # residual + relu
     (1, 17, 30, 128, 128, 1, 0, True, False, True),    # leaky then residual (ChengResBlock)
-    (5, 5, 3, 128, 64, 0, 1, False, True, True),       # no bias, gate multiplicand, tiny images: a tile spans images
-    (1, 1, 1, 32, 64, 0, 0, True, False, False),       # a single pixel
+    (5, 5, 3, 128, 128, 0, 1, False, True, True),      # no bias, gate multiplicand, tiny images: a tile spans images
+    (1, 1, 1, 32, 128, 0, 0, True, False, False),      # a single pixel
     (2, 34, 60, 128, 128, 0, 0, True, False, False),
-    (1, 9, 40, 64, 192, 2, 0, True, False, False),     # c_out 192: three 64-channel tiles
+    (1, 9, 40, 64, 256, 2, 0, True, False, False),     # c_out 256: four 64-channel blocks
     (1, 68, 120, 128, 128, 0, 0, True, False, True),   # the 1/16-resolution shape of 1080p
+    (2, 33, 50, 64, 128, 1, 0, True, False, True),     # interior blocks (lean epilogue) + right-edge / bottom-edge blocks
+    (1, 47, 64, 32, 128, 0, 1, True, False, False),    # leaky after the (absent) residual
+    (1, 32, 48, 32, 256, 2, 0, False, False, False),   # relu, no bias
 ]
 
 
@@ -45,7 +48,9 @@ def _inputs(case, seed):
 def fp32w(oracle):
     from aivc_amd import ops
     prev_h, prev_o = ops.set_precision('fp32w'), oracle.set_precision('fp32w')
+    ops.WINO_ANY_SIZE = oracle.WINO_ANY_SIZE = True  # the kernel on shapes the oracle checks in seconds
     yield
+    ops.WINO_ANY_SIZE = oracle.WINO_ANY_SIZE = False
     ops.set_precision(prev_h)
     oracle.set_precision(prev_o)
 
@@ -65,20 +70,23 @@ def test_hip_equals_oracle_bit_for_bit(idx, cuda, oracle, fp32w):
         variants = [pr[0] for pr in ops.PROFILE]
     finally:
         ops.PROFILE = None
-    assert variants == [305 if co % 128 == 0 else 301], variants
+    assert variants == [301], variants
     assert np.array_equal(got.cpu().numpy(), want), (case, float(np.abs(got.cpu().numpy() - want).max()))
 
 
 def test_weight_transform_equals_oracle(cuda, oracle):
     from aivc_amd import ops
     rng = np.random.default_rng(9)
-    w = (rng.standard_normal((64, 3, 3, 96)) * 3).astype(np.float32)
+    w = (rng.standard_normal((64, 3, 3, 96)) * 3).astype(np.float32)  # (the transform itself takes any c_out % 64 == 0)
     u = ops.winograd_weights(T(w, cuda)).cpu().numpy()
     assert np.array_equal(u, oracle.winograd_weights(w))
     # G g G^T in fp64
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     ref = np.einsum('ik,oklc,jl->oijc', G, w.astype(np.float64), G).reshape(64, 16, 96)
-    assert np.abs(u - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+    # the staging order of include/aivc_hip.h (AIVC_WINO_U_INDEX): [co / 64][ci / 8][p][(ci % 8) / 4][co % 64][ci % 4]
+    img = u.reshape(1, 12, 16, 2, 64, 4)
+    back = np.transpose(img, (0, 4, 2, 1, 3, 5)).reshape(64, 16, 96)
+    assert np.abs(back - ref).max() <= np.abs(ref).max() * 2.0 ** -23
 
 
 def test_error_against_fp64_next_to_version_1(cuda, oracle):
@@ -96,9 +104,11 @@ def test_error_against_fp64_next_to_version_1(cuda, oracle):
     errs = {}
     for mode in ('fp32', 'fp32w'):
         prev = ops.set_precision(mode)
+        ops.WINO_ANY_SIZE = True
         try:
             y = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=1, pad=1).cpu().numpy()
         finally:
+            ops.WINO_ANY_SIZE = False
             ops.set_precision(prev)
         e = np.abs(y - ref) / np.maximum(1.0, np.abs(ref))
         errs[mode] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
@@ -111,7 +121,7 @@ def test_uncovered_layers_keep_version_1_bits(cuda, fp32w):
     from aivc_amd import ops
     rng = np.random.default_rng(12)
     for mode, k, s, pad, ci, co in ((abi.MODE_CONV, 3, 2, 1, 64, 64), (abi.MODE_CONV, 5, 1, 2, 32, 64), (abi.MODE_CONV, 1, 1, 0, 64, 64),
-                                    (abi.MODE_CONV, 3, 1, 1, 16, 64), (abi.MODE_TCONV, 3, 2, 0, 64, 64), (abi.MODE_CONV, 3, 1, 1, 64, 32)):
+                                    (abi.MODE_CONV, 3, 1, 1, 16, 128), (abi.MODE_TCONV, 3, 2, 0, 64, 128), (abi.MODE_CONV, 3, 1, 1, 64, 64)):
         x = T(rng.standard_normal((1, 10, 12, ci)).astype(np.float32), cuda)
         w = T((rng.standard_normal((co, k, k, ci)) / np.sqrt(k * k * ci)).astype(np.float32), cuda)
         y2 = ops.conv2d(x, w, None, mode=mode, stride=s, pad=pad)
@@ -139,3 +149,26 @@ def test_fused_gdn_request_is_two_launches_with_the_oracle_bits(cuda, oracle, fp
         want = oracle.conv2d(x, wt, b, stride=1, pad=1, gdn=(beta, gamma, inverse), res=res)
         got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=1, pad=1, gdn=(T(beta, cuda), T(gamma, cuda), inverse), res=T(res, cuda))
         assert np.array_equal(got.cpu().numpy(), want), inverse
+
+
+def test_size_rule_of_the_version(cuda, oracle):
+    """aivc_winograd_covers: below AIVC_WINO_MIN_PIXELS input pixels a layer is version 1 in version 2 as well (the same rule
+    on both sides: HIP == oracle); at the threshold it is the Winograd launch"""
+    from aivc_amd import ops
+    rng = np.random.default_rng(31)
+    wt = (rng.standard_normal((128, 3, 3, 32)) / 17).astype(np.float32)
+    prev_h, prev_o = ops.set_precision('fp32w'), oracle.set_precision('fp32w')
+    try:
+        for h, w, want in ((128, 128, 301), (64, 255, 101)):
+            x = rng.standard_normal((1, h, w, 32)).astype(np.float32)
+            ops.PROFILE = []
+            got = ops.conv2d(T(x, cuda), T(wt, cuda), None, stride=1, pad=1)
+            torch.cuda.synchronize()
+            variants = [pr[0] for pr in ops.PROFILE]
+            ops.PROFILE = None
+            assert (variants == [301]) == (want == 301), (h, w, variants)
+            assert np.array_equal(got.cpu().numpy(), oracle.conv2d(x, wt, None, stride=1, pad=1)), (h, w)
+    finally:
+        ops.PROFILE = None
+        ops.set_precision(prev_h)
+        oracle.set_precision(prev_o)
