@@ -482,7 +482,38 @@ class FrameCodec:
         return blobs, [[rec[u][f] for f in names] for u in range(len(units))], data_dim
 
     def decode_units(self, gop_blobs, data_dim, device=None, shard=None):
-        """-> [reconstructions (display order) per unit].  shard: as in encode_units (the entropy stage only runs
+        """-> [reconstructions (display order) per unit]; see _decode_units_gen."""
+        return self.decode_units_finish(self.decode_units_begin(gop_blobs, data_dim, device, shard))
+
+    def decode_units_begin(self, gop_blobs, data_dim, device=None, shard=None):
+        """First half of decode_units: parse the records and issue the entropy stage of the WHOLE video on the side
+        streams (when its CDF windows fit, _entropy_budget); nothing is queued on the main stream.  A caller with other
+        main-stream work -- the next clip's encode (src/real_life/encode.py and decode.py are two processes on two
+        machines in a deployment: the decoder of clip i runs while the encoder works on clip i + 1) -- issues it between
+        _begin and _finish: the serial range-coder streams (the I frame's y stream at the head, 0.5 / 2.1 M symbols at
+        1080p / 4K high rate) then decode under that work instead of in front of the first synthesis.
+        -> a handle for decode_units_finish."""
+        g = self._decode_units_gen(gop_blobs, data_dim, device, shard)
+        try:
+            next(g)
+        except StopIteration as e:
+            return ('done', e.value)
+        return ('running', g)
+
+    @staticmethod
+    def decode_units_finish(handle):
+        state, g = handle
+        if state == 'done':
+            return g
+        while True:
+            try:
+                next(g)
+            except StopIteration as e:
+                return e.value
+
+    def _decode_units_gen(self, gop_blobs, data_dim, device=None, shard=None):
+        """-> [reconstructions (display order) per unit] (a generator: yields once per coding-structure group, right
+        after that group's entropy stage has been issued up front; decode_units runs it through).  shard: as in encode_units (the entropy stage only runs
         for this rank's frames; one exchange of the new reconstructions per level).
         Stage 1 entropy-decodes EVERY frame of every unit (entropy_chunk frames at a time: that many
         range-coder streams run concurrently, one wavefront each; the serial coder is off the
@@ -554,6 +585,7 @@ class FrameCodec:
                 for ftype in sorted({gop[f]['type'] for f in names}):
                     issue_items(ftype, [it for level in levels for it in level_items(level, ftype)])
                 ahead = len(levels)
+                yield 'entropy stage issued'  # (decode_units_begin returns here)
             else:
                 for li in range(min(ahead, len(levels))):
                     issue_entropy(levels[li])

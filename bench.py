@@ -259,6 +259,8 @@ def main():
     ap.add_argument('--high-rate-steps', type=int, default=3)
     ap.add_argument('--no-lean-encoder', action='store_true', help="skip the bitstream-only encoder (recon='refs') measured after the headline run (its own object, never `value`)")
     ap.add_argument('--lean-encoder-steps', type=int, default=2)
+    ap.add_argument('--no-pipelined', action='store_true', help='skip the two-clips-in-flight schedule measured after the headline run (its own object, never `value`)')
+    ap.add_argument('--pipelined-steps', type=int, default=3)
     ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
     ap.add_argument('--precision-steps', type=int, default=2)
     ap.add_argument('--contract', choices=('fp32', 'fp32w'), default=os.environ.get('AIVC_BENCH_CONTRACT', 'fp32'),
@@ -546,6 +548,43 @@ def main():
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.width, args.height, model, fc, dev, args.gop, unit)
 
+    # ---- two clips in flight (never the headline): the decoder's entropy stage depends on the bitstream only, so the decode of
+    # clip i is split (FrameCodec.decode_units_begin / _finish) around the ENCODE of clip i + 1: the serial range-coder streams of
+    # clip i (the I frames' y streams at the head) decode on the side streams under that encode instead of in front of the first
+    # synthesis -- the schedule of a deployment, where encoder and decoder are two processes working on consecutive clips.  Same
+    # kernels, same bytes; one clip more of latency.  `value` keeps the strictly serial step (encode, then decode, of one clip).
+    def pipelined_run(codec, n_steps):
+        with torch.no_grad():
+            # correctness of the schedule first: clip 0's decode finished behind clip 1's encode == its encoder's reconstruction
+            b0, r0, dd0 = codec.encode_units(clips[0], args.gop)
+            h0 = codec.decode_units_begin(b0, dd0, dev)
+            b1, r1, dd1 = codec.encode_units(clips[1 % len(clips)], args.gop)
+            d0 = codec.decode_units_finish(h0)
+            d1 = codec.decode_units(b1, dd1, dev)
+            ok = all(torch.equal(d[k], e[k]) for dec_, enc_ in ((d0, r0), (d1, r1)) for du, eu in zip(dec_, enc_) for d, e in zip(du, eu) for k in 'yuv')
+            ok = ok and len(codec.stream_errors()) == 0
+            del d0, d1, r0, r1
+            torch.cuda.synchronize()
+            t0 = time.time()
+            handle = None
+            for i in range(n_steps):
+                blobs, _, dd = codec.encode_units(clips[(args.warmup + i) % len(clips)], args.gop)
+                if handle is not None:
+                    codec.decode_units_finish(handle)
+                handle = codec.decode_units_begin(blobs, dd, dev)
+            codec.decode_units_finish(handle)
+            torch.cuda.synchronize()
+            el = time.time() - t0
+        return {'value': round(n_steps * args.frames / el, 4), 'unit': 'frames/s', 'steps': n_steps, 'clips_in_flight': 2,
+                'ms_per_step': round(el / n_steps * 1e3, 2), 'closed_loop_ok': bool(ok),
+                'vs_headline': round(n_steps * args.frames / el / (clips_done_for_hr / elapsed), 4)}
+
+    pipelined = None
+    if rank == 0 and world == 1 and not args.no_pipelined:
+        pipelined = pipelined_run(fc, args.pipelined_steps)
+        pipelined['note'] = ('decode of clip i split around the encode of clip i + 1 (decode_units_begin / _finish): the entropy stage of a clip runs '
+                             'under the next clip\'s transforms; the serial step stays the headline')
+
     # ---- the high-rate operating point (BASELINE configs[4] names a high-rate model: every y feature map of both
     # networks non-zero, the serial range coder's streams at their longest), same clip, same run, outside `value`
     high_rate = None
@@ -587,6 +626,8 @@ def main():
                      'vs_headline': round(args.high_rate_steps * args.frames / el_hr / (clips_done_for_hr / elapsed), 4),
                      'note': 'same clip and code path with the synthetic model calibrated so that every y feature map of both '
                              'networks is coded: each frame carries two serial range-coder streams of h_y*w_y*%d symbols' % c_y}
+        if not args.no_pipelined:
+            high_rate['pipelined'] = pipelined_run(fc_hr, args.pipelined_steps)
         del model_hr, fc_hr
 
     # ---- bitstream-only encoder (FrameCodec.encode_units(recon='refs'); never the headline: `value` keeps the encoder that
@@ -719,7 +760,7 @@ def main():
             # bytes are unpinned here (no wheel in the image)
             'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
+            'roofline': roofline, 'cpu_baseline': cpu, 'pipelined': pipelined, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
         }
         if other is not None:
             out['weak_scaling'] = other
