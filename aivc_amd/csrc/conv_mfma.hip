@@ -1381,19 +1381,32 @@ static int pick_tile_auto(const aivc_conv_params &p) {
   if (co <= 64 && !t && M >= 65536 && (p.c_in % BK != 0 || p.ksize == 1 || p.stride == 2)) return 6;
   if (co <= 64) return (M >= 250000 && kred >= 96 && p.c_in % BK == 0) ? 2 : 1;
   if (p.gdn) return (t && p.ksize == 3) ? 5 : 0;  // BN must equal c_out = 128
+  // c_out above 64 that is no multiple of 128 (models of other widths: 96, 144, 192 ...; round 6, bench.py --widths): the
+  // score also counts the columns a tile pads -- 192 channels are 1.5 tiles of 128 (a quarter of the matrix work wasted)
+  // but exactly three of 64 -- and the 64-column tiles with four accumulators per wave (256x64 / 128x64) and the 64x128
+  // LDS-DMA tile join the candidates.
   auto score = [&](int bm, int bn, int slots, double base) {
     const long b = blocks(bm, bn);
     const long rounds = (b + slots - 1) / slots;
-    return base * (double)b / (double)(rounds * slots);
+    const double cols = (double)co / (double)(((co + bn - 1) / bn) * bn);
+    return base * cols * (double)b / (double)(rounds * slots);
   };
   if (p.mode == AIVC_MODE_GDN || p.mode == AIVC_MODE_IGDN) return 1;
   double best = score(128, 128, 512, 0.80);  // 176 registers: two workgroups per CU
   int tile = 0;
   const double s1 = score(64, 64, 1536, kred <= 256 ? 0.85 : 0.74);
   if (s1 > best) best = s1, tile = 1;
-  if (t && p.ksize == 3) {
-    const double s5 = score(64, 128, 1024, 0.75);
+  if ((t && p.ksize == 3) || (!r2_rules && p.c_in % BK == 0 && co % 128 != 0)) {
+    const double s5 = score(64, 128, 1024, t && p.ksize == 3 ? 0.75 : 0.80);
     if (s5 > best) best = s5, tile = 5;
+  }
+  if (!r2_rules && co % 128 != 0) {
+    const double s6 = score(128, 64, 1024, 0.76);
+    if (s6 > best) best = s6, tile = 6;
+    if (p.c_in % BK == 0) {
+      const double s2 = score(256, 64, 512, 0.78);
+      if (s2 > best) best = s2, tile = 2;
+    }
   }
   return tile;
 }

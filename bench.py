@@ -265,6 +265,10 @@ def main():
     ap.add_argument('--precision-steps', type=int, default=2)
     ap.add_argument('--contract', choices=('fp32', 'fp32w'), default=os.environ.get('AIVC_BENCH_CONTRACT', 'fp32'),
                     help="version of the fp32 arithmetic contract: 'fp32' = version 1 (tap chains), 'fp32w' = version 2 (Winograd F(2x2,3x3) chains for the stride-1 3x3 layers it covers, include/aivc_hip.h); HIP == CPU oracle bit for bit in both")
+    ap.add_argument('--widths', type=str, default='default',
+                    help="model widths: 'default' (n2 64 / n 128: the stand-in the headline is quoted on), 'w192' (n2 96 / n 192 / c_y 96), 'w144' "
+                         "(n2 72 / n 144 / c_y 72: not multiples of 32), or 'n2=..,n=..,c_y=..,c_short=..,c_z=..,n_h=..'; anything but 'default' is a "
+                         "side measurement (the real widths are unknown, SURVEY F1/F2)")
     ap.add_argument('--tiny', action='store_true', help='tiny model widths (debug only; invalid as a result)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -310,7 +314,15 @@ def main():
     from aivc_amd.func_util.GOP_structure import generate_gop_struct
     ops.set_precision(args.contract)
     from aivc_amd.models import arch
-    widths = arch.TINY_WIDTHS if args.tiny else arch.DEFAULT_WIDTHS
+    presets = {'default': arch.DEFAULT_WIDTHS,
+               'w192': {'n2': 96, 'n': 192, 'c_y': 96, 'c_short': 96, 'c_z': 48, 'n_h': 192},
+               'w144': {'n2': 72, 'n': 144, 'c_y': 72, 'c_short': 72, 'c_z': 36, 'n_h': 144}}
+    if args.widths in presets:
+        widths = presets[args.widths]
+    else:
+        widths = dict(arch.DEFAULT_WIDTHS, **{k: int(v) for k, v in (kv.split('=') for kv in args.widths.split(','))})
+    if args.tiny:
+        widths = arch.TINY_WIDTHS
     seed = 1234
     model = synth.make_model(widths, seed=seed, device=dev)
     active_y = tuple(int(v) for v in args.active_y.split(','))
@@ -766,6 +778,8 @@ def main():
             out['weak_scaling'] = other
         if args.tiny:
             out['invalid'] = 'tiny debug model'
+        if args.widths != 'default':
+            out['side_measurement'] = 'model widths %s instead of the stand-in the headline is quoted on' % widths
         if use_dist and backend != 'nccl':
             out['invalid'] = 'validation run over %s, not RCCL' % backend
         line = json.dumps(out)

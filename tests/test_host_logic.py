@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(ROOT, 'include', 'aivc_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'static inline[^{]*\{.*?\n\}', '', src, flags=re.S)  # (inline rules shared with the oracle: not exports)
     return sorted(set(re.findall(r'\b(?:int|const char \*)\s*(aivc_\w+)\s*\(', src)))
 
 
