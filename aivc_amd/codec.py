@@ -207,6 +207,12 @@ class FrameCodec:
         AIVC_BAND_LEVELS=1 / 0 forces it on / off (every rank must see the same value)."""
         if shard is None or shard.R <= 1 or n_frames >= shard.R:
             return False
+        # Row bands are bit exact because every output element of version 1 of the contract is one chain over its own window
+        # whatever tensor the window is cut from.  Version 2 (Winograd chains, ops.set_precision('fp32w')) ties an output's
+        # chain to the 2 x 2 tile grid of the tensor it is computed in and to that tensor's size (aivc_winograd_covers): a
+        # slab is another tensor -- never banded there.
+        if ops.PRECISION == abi.PREC_FP32_WINO:
+            return False
         force = _os.environ.get('AIVC_BAND_LEVELS')
         if force is not None:
             return force not in ('0', '')

@@ -259,6 +259,8 @@ def main():
     ap.add_argument('--high-rate-steps', type=int, default=3)
     ap.add_argument('--no-lean-encoder', action='store_true', help="skip the bitstream-only encoder (recon='refs') measured after the headline run (its own object, never `value`)")
     ap.add_argument('--lean-encoder-steps', type=int, default=2)
+    ap.add_argument('--no-contract-v2', action='store_true', help="skip version 2 of the fp32 contract ('fp32w': Winograd chains for the stride-1 3x3 layers it covers) measured after the headline run (its own object, never `value`)")
+    ap.add_argument('--contract-v2-steps', type=int, default=2)
     ap.add_argument('--no-pipelined', action='store_true', help='skip the two-clips-in-flight schedule measured after the headline run (its own object, never `value`)')
     ap.add_argument('--pipelined-steps', type=int, default=3)
     ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
@@ -681,6 +683,58 @@ def main():
                                 '(no other frame references them) skip the CodecNet synthesis the headline encoder runs for its PSNR print; '
                                 'same container bytes, the decoder is unchanged; reported beside the headline, never as `value`'}
 
+    # ---- version 2 of the fp32 contract (AIVC_PREC_FP32_WINO, ops.set_precision('fp32w'); never the headline): the stride-1 3x3
+    # layers with c_out % 128 == 0 and >= 16384 input pixels on Winograd F(2x2, 3x3) chains -- still fixed-order fp32 chains, HIP ==
+    # CPU oracle bit for bit (tests/test_gpu_winograd.py), other bits than version 1.  Round 6's kill criterion for making it the
+    # default was 1.5x on the 3x3 128 -> 128 layer; it measures 1.3x (experiments/r06.md), so it stays an option.
+    contract_v2 = None
+    if rank == 0 and world == 1 and args.contract == 'fp32' and not args.no_contract_v2:
+        prev_prec = ops.set_precision('fp32w')
+        try:
+            with torch.no_grad():
+                blobs, enc_recs, dd = fc.encode_units(clips[0], args.gop)
+                dec = fc.decode_units(blobs, dd, dev)
+                v2_closed = all(torch.equal(d[k], e[k]) for du, eu in zip(dec, enc_recs) for d, e in zip(du, eu) for k in 'yuv')
+                v2_errs = len(fc.stream_errors())
+                del dec, enc_recs
+                ops.PROFILE = []
+                ops.PROFILE_DIRECT_EQUIVALENT[:] = [0.0, 0.0]
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for i in range(args.contract_v2_steps):
+                    blobs, _, dd = fc.encode_units(clips[(args.warmup + i) % len(clips)], args.gop)
+                    fc.decode_units(blobs, dd, dev)
+                torch.cuda.synchronize()
+                el_v2 = time.time() - t0
+            wino = [0, 0.0, 0.0]
+            for variant, flops, e0, e1, _shape in ops.PROFILE:
+                if variant == 301:
+                    wino[0] += 1
+                    wino[1] += flops
+                    wino[2] += e0.elapsed_time(e1) * 1e-3
+            replaced, executed = ops.PROFILE_DIRECT_EQUIVALENT
+            ops.PROFILE = None
+        finally:
+            ops.PROFILE = None
+            ops.set_precision(prev_prec)
+        contract_v2 = {
+            'contract': 'fp32w', 'dtype': 'f32', 'value': round(args.contract_v2_steps * args.frames / el_v2, 4), 'unit': 'frames/s',
+            'steps': args.contract_v2_steps, 'ms_per_step': round(el_v2 / args.contract_v2_steps * 1e3, 2),
+            'vs_headline': round(args.contract_v2_steps * args.frames / el_v2 / (clips_done_for_hr / elapsed), 4),
+            'closed_loop_ok': bool(v2_closed), 'stream_errors': v2_errs,
+            'winograd_kernel': {'launches_per_step': wino[0] // max(args.contract_v2_steps, 1),
+                                'ms_per_step': round(wino[2] / args.contract_v2_steps * 1e3, 2),
+                                # executed FLOPs (16 multiplications per 2 x 2 outputs and channel pair) over HIP-event time: the
+                                # matrix pipe's rate, priced against the fp32 MFMA peak
+                                'bound': 'mfma', 'achieved': round(wino[1] / max(wino[2], 1e-9) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS,
+                                'unit': 'TFLOP/s', 'frac': round(wino[1] / max(wino[2], 1e-9) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                'tap_chain_tflop_replaced_per_step': round(replaced / args.contract_v2_steps / 1e12, 3),
+                                'tflop_executed_per_step': round(executed / args.contract_v2_steps / 1e12, 3)},
+            'note': 'version 2 of the fp32 arithmetic contract (include/aivc_hip.h AIVC_PREC_FP32_WINO): same code path and clip with the '
+                    'covered 3x3 layers on Winograd F(2x2,3x3) chains; bit exact against the CPU oracle in the same version, other bits than '
+                    'version 1 (encoder and decoder must agree); a fused GDN behind a covered layer is a second launch; reported beside the '
+                    'headline, never as `value`'}
+
     # ---- the bf16x3 precision MODE (aivc_conv_params.precision; never the headline: `value` stays the fp32 contract):
     # same clip, same model, same code path with the wide convolutions on six bf16 MFMA products per fp32 product
     precision_mode = None
@@ -772,7 +826,7 @@ def main():
             # bytes are unpinned here (no wheel in the image)
             'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu, 'pipelined': pipelined, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
+            'roofline': roofline, 'cpu_baseline': cpu, 'pipelined': pipelined, 'contract_v2': contract_v2, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
         }
         if other is not None:
             out['weak_scaling'] = other

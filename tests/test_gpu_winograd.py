@@ -172,3 +172,43 @@ def test_size_rule_of_the_version(cuda, oracle):
         ops.PROFILE = None
         ops.set_precision(prev_h)
         oracle.set_precision(prev_o)
+
+
+def test_codec_in_version_2_equals_the_oracle_bytes_and_frames(cuda, oracle):
+    """The whole codec (default widths: the layers version 2 covers run at 1/4 resolution, 128 x 128 = AIVC_WINO_MIN_PIXELS
+    pixels for a 512 x 512 frame) in version 2 of the contract: an I + P + B triple coded by the HIP path and by the CPU oracle,
+    both in 'fp32w' -- container bytes equal, decoded frames equal to the oracle's reconstruction, Winograd launches actually
+    taken; and the bytes differ from version 1's (it is another contract: both ends must run the same one)."""
+    from aivc_amd import ops, synth
+    from aivc_amd.models import arch
+    from oracle import codec as ocodec
+    from oracle import spec as ospec
+    model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
+    synth.calibrate_operating_point(model, cuda)
+    frames = synth.synthetic_video(512, 512, 3, seed=9)
+    fc = model.frame_codec()
+    with torch.no_grad():
+        blob1 = fc.assemble_video(fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2'))
+    prev_h, prev_o = ops.set_precision('fp32w'), oracle.set_precision('fp32w')
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            enc = fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2')
+            blob = fc.assemble_video(enc)
+            dec, _, _, _ = fc.decode_video(blob, cuda)
+        torch.cuda.synchronize()
+        n_wino = sum(1 for pr in ops.PROFILE if pr[0] == 301)
+        ops.PROFILE = None
+        assert fc.stream_errors() == []
+        spec = ospec.export_model(model)
+        ref_blob, ref_rec = ocodec.encode_video(spec, frames, '1_GOP_2')
+    finally:
+        ops.PROFILE = None
+        ops.set_precision(prev_h)
+        oracle.set_precision(prev_o)
+    assert n_wino > 0, 'no layer of the codec took the Winograd launch'
+    assert blob == ref_blob
+    for d, r in zip(dec, ref_rec):
+        for k in 'yuv':
+            np.testing.assert_array_equal(d[k][0].cpu().numpy(), r[k])
+    assert blob != blob1
