@@ -1391,7 +1391,14 @@ static int pick_tile_auto(const aivc_conv_params &p) {
     const double cols = (double)co / (double)(((co + bn - 1) / bn) * bn);
     return base * cols * (double)b / (double)(rounds * slots);
   };
-  if (p.mode == AIVC_MODE_GDN || p.mode == AIVC_MODE_IGDN) return 1;
+  // stand-alone (I)GDN launch (K = C: bound by its memory traffic): with 128 channels the 128-column tile reads the input
+  // once as the GEMM operand instead of once per 64-column tile (round 6: the second launch of a Winograd-covered layer,
+  // 4.0 -> see experiments/r06.md); AIVC_GDN_TILE overrides (tuning aid)
+  if (p.mode == AIVC_MODE_GDN || p.mode == AIVC_MODE_IGDN) {
+    static const int gdn_tile = getenv("AIVC_GDN_TILE") ? atoi(getenv("AIVC_GDN_TILE")) : -1;
+    if (gdn_tile >= 0) return gdn_tile;
+    return co == 128 ? 5 : 1;
+  }
   double best = score(128, 128, 512, 0.80);  // 176 registers: two workgroups per CU
   int tile = 0;
   const double s1 = score(64, 64, 1536, kred <= 256 ? 0.85 : 0.74);

@@ -126,8 +126,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   auto issue_u = [&](const Desc &d_, int c) {  // chunk c of block d_ -> U stage c & 1: a straight copy of the chunk image
     const float *src = d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
     const uint32_t d = u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wino_glds16(src, u_off + (uint32_t)(j * 1024), d + (uint32_t)(j * 1024));
+    // four instructions off ONE M0: the instruction offset advances the global and the LDS address alike (the chunk image is
+    // contiguous on both sides)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072"
+                 : : "v"(u_off), "s"(src), "s"(d) : "memory", "m0");
   };
 
   // ---- transform plan: thread = (tile, channel quad, row i of the 4 x 4 positions) -----------------------------------------
@@ -281,6 +287,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       __builtin_amdgcn_s_barrier();
     }
 
+#ifdef WINO_EXP_NOEPI
+    if (kb + 1u < n_mine) { cur = nxt; if (kb + 2u < n_mine) nxt = make_desc(block_of(kb + 2u)); continue; }
+#endif
     // ---- fold: S[a][b] = sum over this wave's positions (ascending, from +0) of T[a][i] T[b][j] M_p ------------------------------
     floatx16 S[4];
 #pragma unroll

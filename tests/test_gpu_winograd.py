@@ -212,3 +212,33 @@ def test_codec_in_version_2_equals_the_oracle_bytes_and_frames(cuda, oracle):
         for k in 'yuv':
             np.testing.assert_array_equal(d[k][0].cpu().numpy(), r[k])
     assert blob != blob1
+
+
+def test_wide_reference_fixtures_in_version_2(cuda, golden):
+    """the reference's own outputs at the hot-path widths (tests/golden/wide_*.npz: CustomConvLayer 3x3 128 -> 128 + GDN, the
+    ChengResBlocks, the attention modules ...) with the covered layers on Winograd chains (size rule lifted: the fixtures are
+    small): version 2 meets the bound the version 1 kernels are held to (2e-5 relative to max(1, |y|)); printed side by side"""
+    from test_wide_golden import NAMES, _build, _run_gpu
+    from aivc_amd import ops
+    worst, took = {}, 0
+    for name in NAMES:
+        g = golden('wide_' + name)
+        m, x, _ = _build(name)
+        errs = []
+        for mode in ('fp32', 'fp32w'):
+            prev = ops.set_precision(mode)
+            ops.WINO_ANY_SIZE = mode == 'fp32w'
+            try:
+                y, variants = _run_gpu(m, x, cuda)
+            finally:
+                ops.WINO_ANY_SIZE = False
+                ops.set_precision(prev)
+            errs.append(float((np.abs(y - g['y']) / np.maximum(1.0, np.abs(g['y']))).max()))
+            if mode == 'fp32w':
+                took += 1 if 301 in variants else 0
+        worst[name] = errs
+    print('\nmax relative error vs the reference outputs, version 1 | version 2 (Winograd where covered):')
+    for k, (e0, e1) in worst.items():
+        print('  %-22s %.2e | %.2e' % (k, e0, e1))
+    assert took >= 3, 'only %d of the wide fixtures took a Winograd launch' % took
+    assert max(e[1] for e in worst.values()) <= 2e-5, worst
