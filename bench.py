@@ -126,10 +126,10 @@ def cpu_baseline(width, height, model, fc, dev, gop_name='1_GOP_32', unit_frames
     spec = ospec.export_model(model)
     frames = synth.synthetic_video(width, height, 3, seed=11)
 
-    def timed(fr, threads):
+    def timed(fr, threads, gop='1_GOP_2'):
         with torch_cpu.torch_convs(threads):
             t0 = time.time()
-            blob, recs = ocodec.encode_video(spec, fr, '1_GOP_2')
+            blob, recs = ocodec.encode_video(spec, fr, gop)
             t1 = time.time()
             dec = ocodec.decode_video(spec, blob)
             t2 = time.time()
@@ -137,17 +137,18 @@ def cpu_baseline(width, height, model, fc, dev, gop_name='1_GOP_32', unit_frames
         return t1 - t0, t2 - t1, closed, len(blob)
 
     # thread count: ATen / oneDNN on batch-1 convolutions does not scale to every hardware thread of a big host (all
-    # 256 threads of the MI355X box measured 19x SLOWER than one thread per pixel: 306 s for the triple) -- the
-    # count is picked by timing the triple at 1/16 of the area, as a user of the reference's --cpu path would tune it
-    w1, h1 = max(64, width // 4 // 16 * 16), max(48, height // 4 // 16 * 16)
-    small = synth.synthetic_video(w1, h1, 3, seed=11)
-    timed(small, min(cores, 8))  # thread pool / oneDNN primitive warm-up
+    # 256 threads of the MI355X box measured 19x SLOWER than one thread per pixel: 306 s for the triple) -- the count is
+    # picked by timing ONE INTRA FRAME AT THE FULL FRAME SIZE (round 6: the sweep ran on a 480x256 triple before and its
+    # optimum, 16 threads, was then applied to 1080p), as a user of the reference's --cpu path would tune it
+    w1, h1 = width, height
+    small = synth.synthetic_video(w1, h1, 1, seed=11)
+    timed(synth.synthetic_video(max(64, width // 4 // 16 * 16), max(48, height // 4 // 16 * 16), 1, seed=11), min(cores, 8), '1_GOP_0')  # thread pool / oneDNN primitive warm-up
     sweep = {}
-    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4), 64, 32, 16, 8, 4}):
+    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4), 64, 32, 16, 8}):
         if t <= cores:
-            e_, d_, _, _ = timed(small, t)
+            e_, d_, _, _ = timed(small, t, '1_GOP_0')
             sweep[t] = round(e_ + d_, 3)
-            if e_ + d_ > 4 * min(sweep.values()):
+            if e_ + d_ > 3 * min(sweep.values()):
                 break  # (counts are tried in ascending order: past the optimum it only gets worse)
     best = min(sweep, key=sweep.get)
     # the timed sample: one whole unit of the bench's structure (AIVC_CPU_BASELINE_FRAMES trims it for quick runs)
@@ -167,7 +168,7 @@ def cpu_baseline(width, height, model, fc, dev, gop_name='1_GOP_32', unit_frames
            'encode_fps': round(n_unit / enc_s, 5), 'decode_fps': round(n_unit / dec_s, 5), 'closed_loop': bool(closed),
            'frames': n_unit, 'thread_sweep_s': {str(k): v for k, v in sweep.items()},
            'sample': 'oracle with torch-CPU transforms (F.conv2d / conv_transpose2d / GDN, torch.set_num_threads(%d): the fastest of '
-                     'the counts swept on a %dx%d triple, host has %d) on %d frames = one full intra-period unit of %s at %dx%d: '
+                     'the counts swept on one intra frame at %dx%d, host has %d) on %d frames = one full intra-period unit of %s at %dx%d: '
                      'encode %.1f s, decode %.1f s (%d bytes)' % (best, w1, h1, cores, n_unit, unit_gop, width, height, enc_s, dec_s, nbytes)}
     e1, d1, c1, _ = timed(frames, 1)
     out['one_core'] = {'value': round(3.0 / (e1 + d1), 6), 'encode_fps': round(3.0 / e1, 6),

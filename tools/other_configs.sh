@@ -2,9 +2,9 @@
 # GPU box: the other BASELINE.json configurations on the same box and binary as the headline line
 # usage: tools/other_configs.sh <out.txt>
 out=$1
-echo "# python bench.py --no-cpu-baseline --no-roofline --no-high-rate --no-precision-mode <flags>, one MI355X, same box" > $out
+echo "# python bench.py --no-cpu-baseline --no-roofline --no-high-rate --no-precision-mode --no-lean-encoder --no-contract-v2 <flags>, one MI355X, same box" > $out
 run() {
-  line=$(timeout 400 python bench.py --no-cpu-baseline --no-roofline --no-high-rate --no-precision-mode "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r = {k: d[k] for k in ('value','coded_frames_per_s','ms_per_step','encode_main_stream_fps_rank0','decode_main_stream_fps_rank0','closed_loop_ok','stream_errors_rank0','bytes_per_frame')}; r['two_clips_in_flight'] = (d.get('pipelined') or {}).get('value'); r['two_clips_closed_loop_ok'] = (d.get('pipelined') or {}).get('closed_loop_ok'); print(r)")
+  line=$(timeout 400 python bench.py --no-cpu-baseline --no-roofline --no-high-rate --no-precision-mode --no-lean-encoder --no-contract-v2 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r = {k: d[k] for k in ('value','coded_frames_per_s','ms_per_step','encode_main_stream_fps_rank0','decode_main_stream_fps_rank0','closed_loop_ok','stream_errors_rank0','bytes_per_frame')}; r['two_clips_in_flight'] = (d.get('pipelined') or {}).get('value'); r['two_clips_closed_loop_ok'] = (d.get('pipelined') or {}).get('closed_loop_ok'); print(r)")
   echo "$* $line" >> $out
 }
 run                                                       # configs[3] on one GPU (the headline workload)

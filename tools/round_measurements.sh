@@ -1,18 +1,26 @@
 #!/bin/bash
-# the measurements DESIGN.md section 7 quotes, all on one box (files named r05_*: rename per round)
+# the measurements DESIGN.md section 7 quotes, all on one box (round 6: files named r06_*)
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd $root
 mkdir -p gpurun_out
+R=r06
 t0=$(date +%s)
-timeout 900 python bench.py > gpurun_out/r05_bench_line.json 2> gpurun_out/r05_bench_line.err
+timeout 1200 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
 echo "bench rc=$? wall=$(( $(date +%s) - t0 )) s"
-python tools/show_bench.py gpurun_out/r05_bench_line.json 2>/dev/null | head -24
+python tools/show_bench.py gpurun_out/${R}_bench_line.json 2>/dev/null | head -30
 cd /tmp && export TMPDIR=/tmp
-timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/r05_kstats -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/gpurun_out/r05_bench_line_under_rocprof.json 2> $root/gpurun_out/r05_under_rocprof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${R}_kstats -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${R}_bench_line_under_rocprof.json 2> $root/gpurun_out/${R}_under_rocprof.err
 cd $root
-f=$(find gpurun_out/r05_kstats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r05_kernel_stats_bench_1080p.csv; head -12 gpurun_out/r05_kernel_stats_bench_1080p.csv | cut -c1-150
-timeout 900 bash tools/pmc_conv.sh r05_dom32 2 BATCH=32 FUSE_GDN=1 > gpurun_out/pmc_dom.log 2>&1
+f=$(find gpurun_out/${R}_kstats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${R}_kernel_stats_bench_1080p.csv; head -14 gpurun_out/${R}_kernel_stats_bench_1080p.csv | cut -c1-150
+rm -rf gpurun_out/${R}_kstats
+timeout 900 bash tools/pmc_conv.sh ${R}_dom32 2 BATCH=32 FUSE_GDN=1 > gpurun_out/pmc_dom.log 2>&1
 tail -3 gpurun_out/pmc_dom.log
-timeout 1500 bash tools/other_configs.sh gpurun_out/r05_other_configs.txt
-timeout 300 python tools/bench_rangecoder.py > gpurun_out/r05_rangecoder.txt 2>&1
-tail -5 gpurun_out/r05_rangecoder.txt
+n=$(python -c "import sys; sys.path.insert(0,'tools'); import conv_probe; print(len(conv_probe.PROBES) - 1)")
+timeout 900 bash tools/pmc_conv.sh ${R}_wino $n BATCH=16 PRECISION=fp32w > gpurun_out/pmc_wino.log 2>&1
+tail -3 gpurun_out/pmc_wino.log
+BATCH=16 python tools/bench_wino.py > gpurun_out/${R}_ab_winograd.txt 2>/dev/null; BATCH=64 python tools/bench_wino.py >> gpurun_out/${R}_ab_winograd.txt 2>/dev/null; cat gpurun_out/${R}_ab_winograd.txt
+timeout 300 python tools/cli_wallclock.py gpurun_out/${R}_cli_wallclock.json 2>/dev/null | tail -1
+for wd in w192 w144; do timeout 600 python bench.py --widths $wd --steps 2 --warmup 1 --no-high-rate --no-lean-encoder --no-precision-mode --no-cpu-baseline --no-pipelined --no-contract-v2 > gpurun_out/${R}_widths_$wd.json 2>/dev/null; done
+timeout 2400 bash tools/other_configs.sh gpurun_out/${R}_other_configs.txt
+timeout 300 python tools/bench_rangecoder.py > gpurun_out/${R}_rangecoder.txt 2>&1
+tail -5 gpurun_out/${R}_rangecoder.txt
