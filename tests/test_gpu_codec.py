@@ -178,9 +178,11 @@ def test_config5_one_full_gop32_unit_2160p(cuda):
     from aivc_amd.models import arch
     model = synth.make_model(arch.DEFAULT_WIDTHS, seed=1234, device=cuda)
     synth.calibrate_operating_point(model, cuda)
-    base = synth.synthetic_video(3840, 2160, 4, seed=9)
-    # 32 frames out of 4 distinct pictures (host RAM: a 4K frame of the generator is 12 MB of float work per call)
-    frames = synth.to_device_frames([base[i % 4] for i in range(32)], cuda)
+    # 32 DISTINCT pictures of the moving pattern, generated on the device (bench.py's generator: the host one is 12 MB of
+    # float work per 4K frame)
+    from bench import gpu_synthetic_unit
+    frames = gpu_synthetic_unit(3840, 2160, 32, 0, cuda, 9)
+    assert len({int(f['y'].long().sum()) for f in frames}) == 32
     fc = FrameCodec(model, max_batch=16)
     with torch.no_grad():
         enc = fc.encode_video(frames, '1_GOP_32')
