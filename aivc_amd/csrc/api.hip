@@ -108,7 +108,7 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   // version 2 of the fp32 contract: a covered layer is computed by the Winograd chain or not at all (never silently by
   // the tap chain: the two differ in the last bits and an encoder / decoder pair must agree)
   if (p->precision == AIVC_PREC_FP32_WINO && aivc_winograd_covers(p)) {
-    if (!p->w_wino) return AIVC_ERR_ARG;
+    if (!p->w_wino || ((uintptr_t)p->w_wino & 15u) || ((uintptr_t)p->x & 15u)) return AIVC_ERR_ARG;  // (16-byte LDS-DMA loads)
     return aivc::conv2d_wino(*p, s);
   }
   // precision mode (never the default): the shapes it covers; everything else runs the fp32 contract
