@@ -2,7 +2,7 @@
 """A/B of the two versions of the fp32 contract on the stride-1 3x3 layers of the 1080p workload (run on the GPU box):
 time per launch, TFLOP/s in direct-equivalent FLOPs (2 * 9 * c_in * c_out per output pixel) for both, and the MATRIX-PIPE
 rate of the Winograd kernel (its executed FLOPs: 2 * 16 / 4 * c_in * c_out per output pixel) against the 157.3 TFLOP/s peak.
-BATCH=n (default 16)."""
+BATCH=n (default 16); WINO_ANY=1 lifts the size rule of the version (rows of shapes the rule excludes are version 1 on both sides otherwise)."""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -22,6 +22,7 @@ def main():
     dev = torch.device('cuda:0')
     nb = int(os.environ.get('BATCH', '16'))
     reps = int(os.environ.get('REPS', '10'))
+    ops.WINO_ANY_SIZE = bool(os.environ.get('WINO_ANY'))  # version 2 below its size rule too (tuning aid)
     for name, ci, co, h, w, with_gdn, with_res in SHAPES:
         x = torch.randn(nb, h, w, ci, device=dev)
         wt = torch.randn(co, 3, 3, ci, device=dev) * 0.03
