@@ -1,4 +1,5 @@
 // api.hip -- library identity, error plumbing and the conv dispatcher.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -21,6 +22,12 @@ int check_launch(const char *what) {
 
 AIVC_EXPORT int aivc_abi_version(void) { return AIVC_ABI_VERSION; }
 AIVC_EXPORT const char *aivc_last_error(void) { return aivc::g_err; }
+
+// tuning aid: AIVC_GDN_RESIDENT=0 sends stand-alone (I)GDN launches to the generic kernel again (bit identical)
+static bool gdn_resident_on() {
+  static const bool on = !(getenv("AIVC_GDN_RESIDENT") && atoi(getenv("AIVC_GDN_RESIDENT")) == 0);
+  return on;
+}
 
 static int validate_conv(const aivc_conv_params *p) {
   if (!p || !p->x || !p->w || !p->y) return AIVC_ERR_ARG;
@@ -72,6 +79,7 @@ AIVC_EXPORT int aivc_conv2d_variant(const aivc_conv_params *p) {
     return aivc::conv2d_mfma_variant(*p);
   }
   if (p->algo == AIVC_ALGO_DIRECT) return 0;
+  if (p->algo == AIVC_ALGO_AUTO && gdn_resident_on() && aivc::gdn_resident_supported(*p)) return 400;
   if (p->algo == AIVC_ALGO_AUTO && aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin_variant(*p);
   if (p->algo == AIVC_ALGO_MFMA || aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma_variant(*p);
   return 0;
@@ -125,6 +133,7 @@ AIVC_EXPORT int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream) {
   }
   if (p->algo == AIVC_ALGO_DIRECT) return aivc::conv2d_direct(*p, s);
   if (p->algo == AIVC_ALGO_MFMA) return aivc::conv2d_mfma(*p, s);
+  if (gdn_resident_on() && aivc::gdn_resident_supported(*p)) return aivc::gdn_resident(*p, s);  // stand-alone (I)GDN: same bits as the GDN-mode launch below
   if (aivc::conv2d_thin_supported(*p)) return aivc::conv2d_thin(*p, s);
   if (aivc::conv2d_mfma_supported(*p)) return aivc::conv2d_mfma(*p, s);
   return aivc::conv2d_direct(*p, s);
