@@ -26,7 +26,7 @@ BALLE_PARAMS = 43
 MAX_MAPS = 256
 RC_MAX_STREAMS = 64
 RATE_LANES = 16384
-WINO_MIN_PIXELS = 16384  # include/aivc_hip.h: AIVC_WINO_MIN_PIXELS
+WINO_MIN_PIXELS = 8000  # include/aivc_hip.h: AIVC_WINO_MIN_PIXELS
 
 FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 

@@ -389,9 +389,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       const float cbias = has_bias ? p.bias[co] : 0.0f;
       const int oy_w = 2 * (8 * cur.byi + 4 * wm) + ph;  // output row of the wave's first tile row (wave-uniform)
       const bool inside_x = 16 * cur.bxi + 16 <= W;
-      if (inside_x && !g_mul && act1 != AIVC_ACT_SIGMOID) {
-        // fast path (every block but the right-edge column): one wave-uniform 64-bit base per tile row, one 32-bit byte
-        // offset per lane, tile column and output column as immediates -- no per-element address arithmetic, no lane masks
+      if (!g_mul && act1 != AIVC_ACT_SIGMOID) {
+        // fast path: one wave-uniform 64-bit base per tile row, one 32-bit byte offset per lane, tile column and output column as
+        // immediates -- no per-element address arithmetic; lane masks only in the right-edge column of an image whose width is
+        // no multiple of 16 (EDGE: the general path below made every output of such a block one dependent residual round
+        // trip -- 160 instead of 43 us per block, which is what kept the kernel at the tap kernel's pace on the 68 x 120 layers)
+        const int cols_left = W - 16 * cur.bxi;  // output columns of this block that exist (wave-uniform)
         typedef __attribute__((address_space(1))) char gchar;
         typedef __attribute__((address_space(1))) float gfloat;
         typedef __attribute__((address_space(1))) const float cgfloat;
@@ -399,9 +402,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         uint32_t lane_b = (uint32_t)(2 * (8 * cur.bxi + 4 * hh)) * c4 + (uint32_t)co * 4u;
         asm volatile("" : "+v"(lane_b));
         const size_t img_b = (size_t)cur.img * (size_t)H * W * c4;
-        auto rows = [&](auto RES, auto KIND) {
+        auto rows = [&](auto RES, auto KIND, auto EDGE) {
           constexpr bool has_res = decltype(RES)::value;
+          constexpr bool edge = decltype(EDGE)::value;
           constexpr int kind = decltype(KIND)::value;  // act1 / act2 combination, see below
+          bool ok[8];  // column 2 (4 hh + rr) + b of the block exists
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) ok[rr * 2 + b] = !edge || 2 * (4 * hh + rr) + b < cols_left;
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int oy = oy_w + 2 * rq;
@@ -414,7 +423,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
               for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) rv[rr * 2 + b] = *reinterpret_cast<cgfloat *>(rb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u));
+                for (int b = 0; b < 2; ++b)
+                  rv[rr * 2 + b] = ok[rr * 2 + b] ? *reinterpret_cast<cgfloat *>(rb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) : 0.0f;
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
 #ifdef WINO_EXP_NOSTORE
                 if (v == 123.456f)
 #endif
-                *reinterpret_cast<gfloat *>(yb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) = v;
+                if (ok[rr * 2 + b]) *reinterpret_cast<gfloat *>(yb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) = v;
               }
           }
         };
@@ -442,17 +452,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         else if (act2 == AIVC_ACT_NONE) kind = act1 == AIVC_ACT_LEAKY ? 1 : 2;
         else if (act1 == AIVC_ACT_NONE) kind = act2 == AIVC_ACT_RELU ? 3 : 4;
         if (kind >= 0 && Cout % 128 == 0) {
-          auto go = [&](auto RES) {
+          auto go = [&](auto RES, auto EDGE) {
             switch (kind) {
-              case 0: rows(RES, integral_constant<int, 0>{}); break;
-              case 1: rows(RES, integral_constant<int, 1>{}); break;
-              case 2: rows(RES, integral_constant<int, 2>{}); break;
-              case 3: rows(RES, integral_constant<int, 3>{}); break;
-              default: rows(RES, integral_constant<int, 4>{}); break;
+              case 0: rows(RES, integral_constant<int, 0>{}, EDGE); break;
+              case 1: rows(RES, integral_constant<int, 1>{}, EDGE); break;
+              case 2: rows(RES, integral_constant<int, 2>{}, EDGE); break;
+              case 3: rows(RES, integral_constant<int, 3>{}, EDGE); break;
+              default: rows(RES, integral_constant<int, 4>{}, EDGE); break;
             }
           };
-          if (g_res) go(integral_constant<bool, true>{});
-          else go(integral_constant<bool, false>{});
+          if (inside_x) {
+            if (g_res) go(integral_constant<bool, true>{}, integral_constant<bool, false>{});
+            else go(integral_constant<bool, false>{}, integral_constant<bool, false>{});
+          } else {
+            if (g_res) go(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+            else go(integral_constant<bool, false>{}, integral_constant<bool, true>{});
+          }
           goto epilogue_done;
         }
       }

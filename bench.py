@@ -59,6 +59,8 @@ def variant_name(v):
         return 'conv_mfma<conv,128x64+tail1x1>'
     if v == 301:
         return 'conv_wino<8x8 tiles,64>'
+    if v == 400:
+        return 'gdn_resident'
     if v >= 1000:
         return 'bf16x3:' + variant_name(v - 1000)
     if v == 191:
@@ -260,14 +262,14 @@ def main():
     ap.add_argument('--high-rate-steps', type=int, default=3)
     ap.add_argument('--no-lean-encoder', action='store_true', help="skip the bitstream-only encoder (recon='refs') measured after the headline run (its own object, never `value`)")
     ap.add_argument('--lean-encoder-steps', type=int, default=2)
-    ap.add_argument('--no-contract-v2', action='store_true', help="skip version 2 of the fp32 contract ('fp32w': Winograd chains for the stride-1 3x3 layers it covers) measured after the headline run (its own object, never `value`)")
+    ap.add_argument('--no-contract-v2', '--no-other-contract', dest='no_contract_v2', action='store_true', help="skip the other version of the fp32 contract (version 1 when the run is version 2 and vice versa) measured after the headline run (its own object `contract_v1` / `contract_v2`, never `value`)")
     ap.add_argument('--contract-v2-steps', type=int, default=2)
     ap.add_argument('--no-pipelined', action='store_true', help='skip the two-clips-in-flight schedule measured after the headline run (its own object, never `value`)')
     ap.add_argument('--pipelined-steps', type=int, default=3)
     ap.add_argument('--no-precision-mode', action='store_true', help='skip the bf16x3 precision mode measured after the headline run (its own object, never `value`)')
     ap.add_argument('--precision-steps', type=int, default=2)
-    ap.add_argument('--contract', choices=('fp32', 'fp32w'), default=os.environ.get('AIVC_BENCH_CONTRACT', 'fp32'),
-                    help="version of the fp32 arithmetic contract: 'fp32' = version 1 (tap chains), 'fp32w' = version 2 (Winograd F(2x2,3x3) chains for the stride-1 3x3 layers it covers, include/aivc_hip.h); HIP == CPU oracle bit for bit in both")
+    ap.add_argument('--contract', choices=('fp32', 'fp32w'), default=os.environ.get('AIVC_BENCH_CONTRACT', os.environ.get('AIVC_CONTRACT', 'fp32w')),
+                    help="version of the fp32 arithmetic contract the run computes in (default: the library's, aivc_amd/ops.py DEFAULT_CONTRACT): 'fp32' = version 1 (tap chains), 'fp32w' = version 2 (Winograd F(2x2,3x3) chains for the stride-1 3x3 layers it covers, include/aivc_hip.h); HIP == CPU oracle bit for bit in both; the other version is measured beside the headline (`contract_v1` / `contract_v2`)")
     ap.add_argument('--widths', type=str, default='default',
                     help="model widths: 'default' (n2 64 / n 128: the stand-in the headline is quoted on), 'w192' (n2 96 / n 192 / c_y 96), 'w144' "
                          "(n2 72 / n 144 / c_y 72: not multiples of 32), or 'n2=..,n=..,c_y=..,c_short=..,c_z=..,n_h=..'; anything but 'default' is a "
@@ -429,9 +431,12 @@ def main():
     row_bands = None
     if shard is not None and shard.R > 1 and os.environ.get('AIVC_BAND_LEVELS') is None and args.warmup > 0 \
             and (shard.R >= 4 or args.width * args.height >= 6000000):
-        shard.band_levels, row_bands = True, 'on (warm-up clip byte-identical to the single-process encode)'
+        if args.contract == 'fp32':
+            shard.band_levels, row_bands = True, 'on (warm-up clip byte-identical to the single-process encode)'
+        else:  # (FrameCodec._banded refuses: a Winograd chain depends on the tile grid and size of the tensor it is computed in)
+            row_bands = 'off: row bands exist under version 1 of the arithmetic contract only (--contract fp32); levels narrower than the group are coded by its first ranks'
     closed_loop, bytes_equal = warm_up()
-    if row_bands and not (closed_loop and bytes_equal is not False):
+    if row_bands and row_bands.startswith('on') and not (closed_loop and bytes_equal is not False):
         shard.band_levels, row_bands = False, 'switched off: the warm-up clip coded in row bands differed from the single-process encode'
         closed_loop, bytes_equal = warm_up()
     if bytes_equal is False:
@@ -684,13 +689,14 @@ def main():
                                 '(no other frame references them) skip the CodecNet synthesis the headline encoder runs for its PSNR print; '
                                 'same container bytes, the decoder is unchanged; reported beside the headline, never as `value`'}
 
-    # ---- version 2 of the fp32 contract (AIVC_PREC_FP32_WINO, ops.set_precision('fp32w'); never the headline): the stride-1 3x3
-    # layers with c_out % 128 == 0 and >= 16384 input pixels on Winograd F(2x2, 3x3) chains -- still fixed-order fp32 chains, HIP ==
-    # CPU oracle bit for bit (tests/test_gpu_winograd.py), other bits than version 1.  Round 6's kill criterion for making it the
-    # default was 1.5x on the 3x3 128 -> 128 layer; it measures 1.3x (experiments/r06.md), so it stays an option.
+    # ---- the OTHER version of the fp32 contract, beside the headline (never `value`).  Version 2 (AIVC_PREC_FP32_WINO,
+    # 'fp32w', the library's default since round 6): the stride-1 3x3 layers with c_out % 128 == 0 and >= AIVC_WINO_MIN_PIXELS input
+    # pixels on Winograd F(2x2, 3x3) chains -- still fixed-order fp32 chains, HIP == CPU oracle bit for bit
+    # (tests/test_gpu_winograd.py), other bits than version 1 (the 9-tap chains, 'fp32').
     contract_v2 = None
-    if rank == 0 and world == 1 and args.contract == 'fp32' and not args.no_contract_v2:
-        prev_prec = ops.set_precision('fp32w')
+    other_contract = 'fp32' if args.contract == 'fp32w' else 'fp32w'
+    if rank == 0 and world == 1 and not args.no_contract_v2:
+        prev_prec = ops.set_precision(other_contract)
         try:
             with torch.no_grad():
                 blobs, enc_recs, dd = fc.encode_units(clips[0], args.gop)
@@ -719,22 +725,24 @@ def main():
             ops.PROFILE = None
             ops.set_precision(prev_prec)
         contract_v2 = {
-            'contract': 'fp32w', 'dtype': 'f32', 'value': round(args.contract_v2_steps * args.frames / el_v2, 4), 'unit': 'frames/s',
+            'contract': other_contract, 'dtype': 'f32', 'value': round(args.contract_v2_steps * args.frames / el_v2, 4), 'unit': 'frames/s',
             'steps': args.contract_v2_steps, 'ms_per_step': round(el_v2 / args.contract_v2_steps * 1e3, 2),
             'vs_headline': round(args.contract_v2_steps * args.frames / el_v2 / (clips_done_for_hr / elapsed), 4),
             'closed_loop_ok': bool(v2_closed), 'stream_errors': v2_errs,
-            'winograd_kernel': {'launches_per_step': wino[0] // max(args.contract_v2_steps, 1),
-                                'ms_per_step': round(wino[2] / args.contract_v2_steps * 1e3, 2),
-                                # executed FLOPs (16 multiplications per 2 x 2 outputs and channel pair) over HIP-event time: the
-                                # matrix pipe's rate, priced against the fp32 MFMA peak
-                                'bound': 'mfma', 'achieved': round(wino[1] / max(wino[2], 1e-9) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS,
-                                'unit': 'TFLOP/s', 'frac': round(wino[1] / max(wino[2], 1e-9) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                'tap_chain_tflop_replaced_per_step': round(replaced / args.contract_v2_steps / 1e12, 3),
-                                'tflop_executed_per_step': round(executed / args.contract_v2_steps / 1e12, 3)},
-            'note': 'version 2 of the fp32 arithmetic contract (include/aivc_hip.h AIVC_PREC_FP32_WINO): same code path and clip with the '
-                    'covered 3x3 layers on Winograd F(2x2,3x3) chains; bit exact against the CPU oracle in the same version, other bits than '
-                    'version 1 (encoder and decoder must agree); a fused GDN behind a covered layer is a second launch; reported beside the '
-                    'headline, never as `value`'}
+            'note': 'the other version of the fp32 arithmetic contract (include/aivc_hip.h; version 1 = 9-tap chains everywhere, version 2 = '
+                    'AIVC_PREC_FP32_WINO: the covered 3x3 layers on Winograd F(2x2,3x3) chains, a fused GDN behind a covered layer as a second '
+                    'launch): same code path and clip; each version is bit exact against the CPU oracle of the same version, their bits differ '
+                    '(encoder and decoder must agree); reported beside the headline, never as `value`'}
+        if other_contract == 'fp32w':
+            contract_v2['winograd_kernel'] = {
+                'launches_per_step': wino[0] // max(args.contract_v2_steps, 1),
+                'ms_per_step': round(wino[2] / args.contract_v2_steps * 1e3, 2),
+                # executed FLOPs (16 multiplications per 2 x 2 outputs and channel pair) over HIP-event time: the
+                # matrix pipe's rate, priced against the fp32 MFMA peak
+                'bound': 'mfma', 'achieved': round(wino[1] / max(wino[2], 1e-9) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(wino[1] / max(wino[2], 1e-9) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                'tap_chain_tflop_replaced_per_step': round(replaced / args.contract_v2_steps / 1e12, 3),
+                'tflop_executed_per_step': round(executed / args.contract_v2_steps / 1e12, 3)}
 
     # ---- the bf16x3 precision MODE (aivc_conv_params.precision; never the headline: `value` stays the fp32 contract):
     # same clip, same model, same code path with the wide convolutions on six bf16 MFMA products per fp32 product
@@ -827,7 +835,7 @@ def main():
             # bytes are unpinned here (no wheel in the image)
             'closed_loop_scope': 'encoder and decoder of this build only',
             'parity_checked': bool(cpu and cpu.get('parity_checked')), 'quality': quality,
-            'roofline': roofline, 'cpu_baseline': cpu, 'pipelined': pipelined, 'contract_v2': contract_v2, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
+            'roofline': roofline, 'cpu_baseline': cpu, 'pipelined': pipelined, ('contract_v1' if args.contract == 'fp32w' else 'contract_v2'): contract_v2, 'high_rate': high_rate, 'bitstream_only_encoder': lean_encoder, 'precision_mode': precision_mode,
         }
         if other is not None:
             out['weak_scaling'] = other

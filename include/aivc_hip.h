@@ -152,8 +152,9 @@ typedef struct aivc_conv_params {
  *                  or subtraction each),  T[0] = (1, 1, 1, 0), T[1] = (0, 1, -1, -1)
  * then the epilogue of the contract unchanged (bias, fused gdn, act1, mul, res, act2).  U = aivc_winograd_weights(w). */
 #define AIVC_PREC_FP32_WINO 2
-#define AIVC_WINO_MIN_PIXELS 16384 /* h_in * w_in from which the version applies: below it the 16 x 16-pixel blocks of the kernel
-                                    * quantise the image badly and a launch is a handful of blocks per CU (68 x 120: no gain) */
+#define AIVC_WINO_MIN_PIXELS 8000 /* h_in * w_in from which the version applies: below it the 16 x 16-pixel blocks of the kernel
+                                   * quantise the image badly and a launch is a handful of blocks per CU (34 x 60: no gain; the 68 x 120
+                                   * layers of a 1080p frame are covered: x1.26 ... 1.42 on batches of 16 ... 64 frames) */
 #define AIVC_CONV_WINO_ANY_SIZE 2 /* aivc_conv_params.flags: version 2 whatever the image size (the tests drive the kernel on shapes the oracle checks in seconds) */
 static inline int aivc_winograd_covers(const aivc_conv_params *p) {
   return p->mode == AIVC_MODE_CONV && p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0 &&

@@ -90,7 +90,8 @@ def pack_weight(w_oihw, c_store=None, transposed=False):
     return np.ascontiguousarray(w)
 
 
-PRECISION = abi.PREC_FP32  # version of the fp32 contract the conv family computes in (set_precision)
+# version of the fp32 contract the conv family computes in (set_precision); the default follows the product's (aivc_amd/ops.py)
+PRECISION = {'fp32': abi.PREC_FP32, 'fp32w': abi.PREC_FP32_WINO}[os.environ.get('AIVC_CONTRACT', 'fp32w')]
 WINO_ANY_SIZE = False  # tests: version 2 below AIVC_WINO_MIN_PIXELS too (aivc_conv_params.flags)
 
 

@@ -54,12 +54,20 @@ def test_bench_one_unit_over_four_ranks_level_sharding_and_bands(cuda):
     """ONE intra-period unit on 4 ranks (what configs[4] asks of 8 GPUs): one group, the frames of a dependency level
     dealt over its ranks, the levels narrower than the group in row bands (4 ranks: the automatic rule) after the
     warm-up clip came out byte-identical to the single-rank encode"""
-    out, err = _run(4, ['--frames', '16', '--gop', '1_GOP_16'])
-    assert out['n_gpus'] == 4 and out['scaling'] == 'strong'
+    out, err = _run(4, ['--frames', '16', '--gop', '1_GOP_16', '--contract', 'fp32'])  # (row bands: version 1 of the contract only)
+    assert out['n_gpus'] == 4 and out['scaling'] == 'strong' and out['arithmetic_contract'] == 'fp32'
     assert out['bytes_equal_single_rank'] is True and out['closed_loop_ok'] is True
     assert out['config']['units_per_step'] == 1
     assert out['row_bands'] is not None and out['row_bands'].startswith('on')
     assert 'x4' in out['config']['parallelism']
+
+
+def test_bench_one_unit_over_four_ranks_in_the_default_contract(cuda):
+    """the same in the default (version 2) contract: level sharding only, row bands reported off, bytes still those of one rank"""
+    out, err = _run(4, ['--frames', '16', '--gop', '1_GOP_16'])
+    assert out['n_gpus'] == 4 and out['scaling'] == 'strong' and out['arithmetic_contract'] == 'fp32w'
+    assert out['bytes_equal_single_rank'] is True and out['closed_loop_ok'] is True
+    assert out['row_bands'] is not None and out['row_bands'].startswith('off')
 
 
 def test_bench_weak_scaling_flag(cuda):

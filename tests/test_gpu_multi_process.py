@@ -36,8 +36,10 @@ def _setup(n_units, gop, w=80, h=48, default_widths=False):
     return model, units, dev
 
 
-def _worker(rank, world, port, q, n_units, gop, w, h, default_widths):
+def _worker(rank, world, port, q, n_units, gop, w, h, default_widths, contract=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if contract:  # row bands exist under version 1 of the arithmetic contract only (FrameCodec._banded)
+        os.environ['AIVC_CONTRACT'] = contract
     if w * h < 6000000:
         os.environ['AIVC_BAND_LEVELS'] = '1'  # small frames: the automatic rule would not band 2 ranks (FrameCodec._banded)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), AIVC_DIST_BACKEND='gloo')
@@ -68,7 +70,7 @@ def test_processes_on_one_gpu_match_single_process(n_units, gop, world, layout, 
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_units, gop, w, h, default_widths)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_units, gop, w, h, default_widths, 'fp32' if banded else None)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
@@ -80,11 +82,17 @@ def test_processes_on_one_gpu_match_single_process(n_units, gop, world, layout, 
     # row bands were (not) used, and what travelled were halo rows, not activations
     for r in res:
         assert (r[4] is not None and r[4][0] > 0) == banded
+    from aivc_amd import ops
     model, units, dev = _setup(n_units, gop, w, h, default_widths)
     fc = model.frame_codec()
-    with torch.no_grad():
-        ref_blobs, ref_recs, dd = fc.encode_units(units, gop)
-        ref_dec = fc.decode_units(ref_blobs, dd, dev)
+    prev = ops.set_precision('fp32') if banded else None  # the single-process reference in the workers' contract
+    try:
+        with torch.no_grad():
+            ref_blobs, ref_recs, dd = fc.encode_units(units, gop)
+            ref_dec = fc.decode_units(ref_blobs, dd, dev)
+    finally:
+        if prev:
+            ops.set_precision(prev)
     assert res[0][1] == ref_blobs
     for r in res:
         for u, got in r[3].items():
