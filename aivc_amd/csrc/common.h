@@ -135,7 +135,7 @@ bool conv2d_wino_supported(const aivc_conv_params &p);  // conv_wino.hip: AIVC_P
 int conv2d_wino(const aivc_conv_params &p, hipStream_t s);
 int conv2d_wino_variant(const aivc_conv_params &p);  // 305: 64 tiles x 128 channels, 301: 64 x 64
 int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t s);
-bool gdn_resident_supported(const aivc_conv_params &p);  // gdn.hip: stand-alone (I)GDN of 64 / 128 / 192 channels, gamma resident in registers
+bool gdn_resident_supported(const aivc_conv_params &p);  // gdn.hip: stand-alone (I)GDN of 64 / 128 channels, gamma resident in registers
 int gdn_resident(const aivc_conv_params &p, hipStream_t s);  // variant 400
 bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p);
 int conv_images(const aivc_image_src *src, int n_img, const aivc_conv_params &p, hipStream_t s);  // conv_images.hip

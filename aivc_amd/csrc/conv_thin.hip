@@ -188,12 +188,14 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, g = lane >> 4;
   const int row = wave >> 1;
-  const int nb = NB == 2 ? (wave & 1) : 0, mg0 = NB == 2 ? 0 : (wave & 1);
+  // c_out 6 (two N blocks): block nb holds the two classes with pxc = nb (12 of its 16 columns) -- the neighbours of the column
+  // dx = LO carry no tap of the pxc = 1 classes, so the waves of block 1 skip those steps (6 of 9 neighbours instead of 9:
+  // 15 instead of 18 MFMA steps per pixel group and channel quadruple over the pair); waves w and w + 4 share a SIMD: one of each
+  const int nb = NB == 2 ? ((wave ^ (wave >> 2)) & 1) : 0, mg0 = NB == 2 ? 0 : (wave & 1);
 
   // ---- this lane's output column and its B operand ------------------------------------------------
-  const int nc = nb * 16 + col;
-  const bool colok = nc < 4 * CO;
-  const int cls = colok ? nc / CO : 0, o = colok ? nc % CO : 0;
+  const bool colok = NB == 2 ? col < 2 * CO : col < 4 * CO;
+  const int cls = !colok ? 0 : (NB == 2 ? 2 * (col / CO) + nb : col / CO), o = colok ? col % CO : 0;
   const int pyc = cls >> 1, pxc = cls & 1;
   float breg[NSTEP][4];
 #pragma unroll
@@ -374,19 +376,22 @@ __global__ __launch_bounds__(512) void thin_mfma_kernel(aivc_conv_params p, int 
     floatx4 acc[NMG];
 #pragma unroll
     for (int mg = 0; mg < NMG; ++mg) acc[mg] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    const bool skip_lo = NB == 2 && nb == 1;  // (wave-uniform) this wave's columns have no tap at dx = LO
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       const int t = step / G16, j16 = step % G16;
       const int dy = HI - t / ND, dx = HI - t % ND;
-      float4 af[NMG];
-#pragma unroll
-      for (int mg = 0; mg < NMG; ++mg)
-        af[mg] = *reinterpret_cast<const float4 *>(ap + ((dy - LO) * PW + (dx - LO) + mg * 16) * PS + j16 * 4);
       if (step == EMIT_AT && have_prev) emit(t_prev, pacc);
       if (step == STORE_AT && next < ntiles) {
         stage_store(smem + (cur ^ 1) * PATCH);  // the patch of `next` (origin t_load)
         if (next + G < ntiles) stage_load(advance(t_load));
       }
+      // kx of the pxc = 1 classes at dx = LO lies beyond the kernel: exact no-ops, not issued (one uniform branch per neighbour column)
+      if (NB == 2 && 1 + TPAD - 2 * dx >= KS && skip_lo) continue;
+      float4 af[NMG];
+#pragma unroll
+      for (int mg = 0; mg < NMG; ++mg)
+        af[mg] = *reinterpret_cast<const float4 *>(ap + ((dy - LO) * PW + (dx - LO) + mg * 16) * PS + j16 * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll

@@ -43,7 +43,8 @@ __device__ __forceinline__ void gdn_glds16(const float *base, uint32_t voff, uin
 
 __device__ __forceinline__ int gdn_swz(int row) { return (row & 15) ^ ((row & 4) << 1); }
 
-// C = 64: 2 channel blocks x 2 row blocks = 4 waves (one accumulator each); C = 128: 4 waves x 2 row blocks; C = 192: 6 waves x 2
+// C = 64: 2 channel blocks x 2 row blocks = 4 waves (one accumulator each); C = 128: 4 waves x 2 row blocks (C = 192: 6 waves x 2 --
+// measured slower than the generic kernel, not dispatched)
 template <int C>
 struct GdnCfg {
   static constexpr int NB = C / 32;             // channel blocks of 32
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(64 * GdnCfg<C>::NW, GdnCfg<C>::WGS) void gdn_reside
   }
 }
 
-// what the kernel covers: a stand-alone (I)GDN launch (ksize 1, c_in == c_out) of 64 / 128 / 192 channels, no activation, no gate
+// what the kernel covers: a stand-alone (I)GDN launch (ksize 1, c_in == c_out) of 64 / 128 channels, no activation, no gate
 bool gdn_resident_supported(const aivc_conv_params &p) {
   if (p.mode != AIVC_MODE_GDN && p.mode != AIVC_MODE_IGDN) return false;
-  if (p.c_in != 64 && p.c_in != 128 && p.c_in != 192) return false;
+  if (p.c_in != 64 && p.c_in != 128) return false;  // (192 channels: gamma alone is 96 registers, one workgroup per CU: 4.1 against 3.85 ms generic)
   if (p.c_out != p.c_in || !p.bias || p.mul || p.act1 != AIVC_ACT_NONE || p.act2 != AIVC_ACT_NONE) return false;
   if (((uintptr_t)p.x & 15u) || ((uintptr_t)p.w & 15u)) return false;
   const uint64_t pix = (uint64_t)p.n * p.h_in * p.w_in;
@@ -278,11 +279,8 @@ int gdn_resident(const aivc_conv_params &p, hipStream_t s) {
     if (inv) return res ? gdn_launch<C, true, true>(a, s, cus) : gdn_launch<C, true, false>(a, s, cus);
     return res ? gdn_launch<C, false, true>(a, s, cus) : gdn_launch<C, false, false>(a, s, cus);
   };
-  switch (p.c_in) {
-    case 64: return go(std::integral_constant<int, 64>{});
-    case 128: return go(std::integral_constant<int, 128>{});
-    default: return go(std::integral_constant<int, 192>{});
-  }
+  if (p.c_in == 64) return go(std::integral_constant<int, 64>{});
+  return go(std::integral_constant<int, 128>{});
 }
 
 }  // namespace aivc

@@ -26,7 +26,7 @@ for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k = r.get('Kernel_Name', '')
-        if 'conv_mfma' not in k and 'thin' not in k and 'conv_wino' not in k:
+        if 'conv_mfma' not in k and 'thin' not in k and 'conv_wino' not in k and 'gdn_resident' not in k:
             continue
         per[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, d in per.items():

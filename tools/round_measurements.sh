@@ -18,6 +18,13 @@ tail -3 gpurun_out/pmc_dom.log
 n=$(python -c "import sys; sys.path.insert(0,'tools'); import conv_probe; print(len(conv_probe.PROBES) - 1)")
 timeout 900 bash tools/pmc_conv.sh ${R}_wino $n BATCH=16 PRECISION=fp32w > gpurun_out/pmc_wino.log 2>&1
 tail -3 gpurun_out/pmc_wino.log
+timeout 900 bash tools/pmc_conv.sh ${R}_wino_68x120 11 BATCH=64 PRECISION=fp32w > gpurun_out/pmc_wino68.log 2>&1   # right-edge column in the masked fast epilogue
+tail -3 gpurun_out/pmc_wino68.log
+timeout 900 bash tools/pmc_conv.sh ${R}_gdn_resident 3 BATCH=32 > gpurun_out/pmc_gdn.log 2>&1                          # csrc/gdn.hip (variant 400)
+tail -3 gpurun_out/pmc_gdn.log
+python tools/bench_gdn.py 128 64 272 480 > gpurun_out/${R}_gdn.txt 2>/dev/null; python tools/bench_gdn.py 64 64 272 480 >> gpurun_out/${R}_gdn.txt 2>/dev/null; cat gpurun_out/${R}_gdn.txt
+python tools/wino_sizes.py > gpurun_out/${R}_wino_sizes.txt 2>/dev/null; cat gpurun_out/${R}_wino_sizes.txt
+python tools/enc_vs_dec_kernels.py 2>/dev/null | tail -3
 BATCH=16 python tools/bench_wino.py > gpurun_out/${R}_ab_winograd.txt 2>/dev/null; BATCH=64 python tools/bench_wino.py >> gpurun_out/${R}_ab_winograd.txt 2>/dev/null; cat gpurun_out/${R}_ab_winograd.txt
 timeout 300 python tools/cli_wallclock.py gpurun_out/${R}_cli_wallclock.json 2>/dev/null | tail -1
 for wd in w192 w144; do timeout 600 python bench.py --widths $wd --steps 2 --warmup 1 --no-high-rate --no-lean-encoder --no-precision-mode --no-cpu-baseline --no-pipelined --no-contract-v2 > gpurun_out/${R}_widths_$wd.json 2>/dev/null; done
