@@ -6,7 +6,7 @@ oracle/oracle.py (tests only).
 """
 import ctypes as C
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_FP32, PREC_BF16X3, PREC_FP32_WINO = 0, 1, 2  # aivc_conv_params.precision
 
 AIVC_OK = 0
@@ -107,6 +107,7 @@ PROTOTYPES = {
     'aivc_gdn_reparam': [_f, _f, _i32, _fl, _fl, _fl, _f, _f],
     'aivc_split_weights_bf16x3': [_f, _i32, _i32, C.c_void_p],
     'aivc_winograd_weights': [_f, _i32, _i32, _f],
+    'aivc_winograd_weights_poly5': [_f, _i32, _i32, _f],
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],

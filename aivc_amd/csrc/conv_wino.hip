@@ -40,6 +40,8 @@ struct WinoArgs {
   int nby, nbx;  // blocks of 8 x 8 tiles per image
   int gy;        // blocks of 64 output channels
   int total;     // blocks in all: n * nby * nbx * gy
+  int poly;      // 1: the 5x5 stride-2 convolution as four stride-1 3x3 convolutions of the input's polyphase components
+  int cpp_shift; // log2 of the chunks per phase (c_in / 8)
 };
 
 __device__ __forceinline__ void wino_glds16(const float *base, uint32_t voff, uint32_t lds_dst) {
@@ -53,6 +55,8 @@ constexpr int WINO_V_POS = 2 * WINO_V_QUAD;
 constexpr int WINO_V_STAGE = 16 * WINO_V_POS;
 constexpr int WINO_LDS = 2 * (WINO_RAW_STAGE + WINO_U_STAGE + WINO_V_STAGE);
 
+// POLY: the polyphase form of the 5x5 stride-2 layers (a separate instantiation: the stride-1 3x3 kernel pays nothing for it)
+template <bool POLY>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wsmem[];
   char *raw = wsmem, *Us = wsmem + 2 * WINO_RAW_STAGE, *Vs = Us + 2 * WINO_U_STAGE;
@@ -62,7 +66,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;  // waves w and w + 4 (one SIMD) = the two position halves of a sub-tile
-  const int H = p.h_in, W = p.w_in, Cin = p.c_in, Cout = p.c_out;
+  // H x W: the pixel grid the blocks walk = the OUTPUT's (stride 1: also the input's); Hi x Wi: the input's.  Polyphase form
+  // (a.poly, 5x5 stride 2, include/aivc_hip.h): the reduction runs over 4 phases x c_in channels, chunk c belongs to phase
+  // c >> cpp_shift = 2 py + px, whose patch pixel (y, x) is input pixel (clamp(2 y + py), clamp(2 x + px)) -- the replicate
+  // padding of the ORIGINAL image -- and whose 3x3 kernel is the phase's taps padded with zeros: positions with i == 3 (py = 1)
+  // or j == 3 (px = 1) have U = 0 and are not issued (49 instead of 64 of the 4 x 16 position products).
+  const int H = p.h_out, W = p.w_out, Hi = p.h_in, Wi = p.w_in, Cin = p.c_in, Cout = p.c_out;
+  constexpr int poly = POLY ? 1 : 0;
+  const int cpp_shift = a.cpp_shift, cpp_mask = (1 << a.cpp_shift) - 1;
 
   // Persistent workgroups (one per CU: a.nwg of them) walk the blocks.  The dispatcher deals consecutive workgroup ids
   // round-robin to the 8 XCDs (each with a private L2): workgroup b sits on XCD b & 7 and takes blocks of that XCD's
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   // what the epilogue needs (coordinates)
   struct Desc {
     const float *xbase, *ubase;
-    uint32_t r_off[2];
+    uint32_t r_off[2];  // stride-1 form: per-lane byte offsets of the block's raw patch (the polyphase form keeps those of the phase being issued)
     int img, byi, bxi, cb;
   };
   // raw: instruction k of 11 writes slots 64 k .. 64 k + 63; wave w issues k = w and, for w < 3, k = w + 8.  slot = (plane *
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
     s_py[k] = 2 * hy + (plane >> 1);
     s_px[k] = 2 * hx + (plane & 1);
   }
+  const int nch = poly ? 4 * (Cin >> 3) : (Cin >> 3);  // chunks of 8 (virtual) input channels per block
   auto make_desc = [&](uint32_t blk) {
     Desc d;
     d.cb = (int)(blk % (uint32_t)a.gy);
@@ -101,31 +113,55 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
     rest /= (uint32_t)a.nbx;
     d.byi = (int)(rest % (uint32_t)a.nby);
     d.img = (int)(rest / (uint32_t)a.nby);
-    d.xbase = p.x + (size_t)d.img * (size_t)H * W * Cin;                         // this image (32-bit byte offsets inside it)
-    d.ubase = p.w_wino + (size_t)d.cb * (size_t)(Cin / 8) * (WINO_U_STAGE / 4);  // this channel block's chunk images
+    d.xbase = p.x + (size_t)d.img * (size_t)Hi * Wi * Cin;                       // this image (32-bit byte offsets inside it)
+    d.ubase = p.w_wino + (size_t)d.cb * (size_t)nch * (WINO_U_STAGE / 4);        // this channel block's chunk images
+    if constexpr (!POLY) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int iy = max(min(16 * d.byi - 1 + s_py[k], H - 1), 0), ix = max(min(16 * d.bxi - 1 + s_px[k], W - 1), 0);
-      d.r_off[k] = ((uint32_t)(iy * W + ix) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
+      for (int k = 0; k < 2; ++k) {
+        const int iy = max(min(16 * d.byi - 1 + s_py[k], Hi - 1), 0), ix = max(min(16 * d.bxi - 1 + s_px[k], Wi - 1), 0);
+        d.r_off[k] = ((uint32_t)(iy * Wi + ix) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
+      }
     }
     return d;
+  };
+  // per-lane byte offsets of the raw patch of block d_ in phase ph2 = 2 py + px (stride 1: phase 0, step 1): recomputed when the
+  // issue stream enters a phase (every c_in / 8 chunks), kept in two registers in between
+  uint32_t iss_off[2];
+  auto patch_offsets = [&](const Desc &d_, int ph2) {
+    const int st = poly ? 2 : 1, py = ph2 >> 1, px = ph2 & 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int iy = max(min(st * (16 * d_.byi - 1 + s_py[k]) + py, Hi - 1), 0), ix = max(min(st * (16 * d_.bxi - 1 + s_px[k]) + px, Wi - 1), 0);
+      iss_off[k] = ((uint32_t)(iy * Wi + ix) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
+    }
   };
   Desc cur = make_desc(block_of(0)), nxt = n_mine > 1u ? make_desc(block_of(1)) : cur;
 
   const uint32_t r_dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
   const uint32_t u_dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(2 * WINO_RAW_STAGE) + (uint32_t)wave * 4096u);
   const uint32_t u_off = (uint32_t)(wave * 4096 + lane * 16);
-  const int nch = Cin >> 3;
-  auto issue_raw = [&](const Desc &d_, int c) {  // chunk c of block d_ -> raw stage c & 1
-    const float *src = d_.xbase + 8 * c;
-    const uint32_t *r_off = d_.r_off;
+  auto uniform_ptr = [](const float *q) -> const float * {  // (wave-uniform by construction: tell the compiler, the DMA wants a scalar base)
+    const uint64_t v = (uint64_t)(uintptr_t)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+  };
+  auto issue_raw = [&](const Desc &d_, int c) {  // chunk c of block d_ -> raw stage c & 1 (chunks are issued in order)
     const uint32_t d = r_dst + (uint32_t)((c & 1) * WINO_RAW_STAGE);
-    wino_glds16(src, r_off[0], d);
-    if (wave < 3) wino_glds16(src, r_off[1], d + 8192u);
+    if constexpr (POLY) {
+      if ((c & cpp_mask) == 0) patch_offsets(d_, c >> cpp_shift);  // the issue stream enters a phase
+      const float *src = uniform_ptr(d_.xbase + 8 * (c & cpp_mask));
+      const uint32_t du = __builtin_amdgcn_readfirstlane(d);  // (under register pressure the compiler parks the uniform in a VGPR)
+      wino_glds16(src, iss_off[0], du);
+      if (wave < 3) wino_glds16(src, iss_off[1], du + 8192u);
+    } else {
+      const float *src = d_.xbase + 8 * c;
+      wino_glds16(src, d_.r_off[0], d);
+      if (wave < 3) wino_glds16(src, d_.r_off[1], d + 8192u);
+    }
   };
   auto issue_u = [&](const Desc &d_, int c) {  // chunk c of block d_ -> U stage c & 1: a straight copy of the chunk image
-    const float *src = d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
-    const uint32_t d = u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
+    const float *src = POLY ? uniform_ptr(d_.ubase + (size_t)c * (WINO_U_STAGE / 4)) : d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
+    const uint32_t d = POLY ? __builtin_amdgcn_readfirstlane(u_dst + (uint32_t)((c & 1) * WINO_U_STAGE)) : u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
     // four instructions off ONE M0: the instruction offset advances the global and the LDS address alike (the chunk image is
     // contiguous on both sides)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
@@ -216,7 +252,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   // instruction stream per wave in which matrix and vector / LDS work alternate, so that the two waves of a SIMD fill each
   // other's gaps without any phase arrangement
   // FIRST: the block's first chunk starts its accumulators from the inline constant 0 (no clearing pass after the fold)
-  auto multiply = [&](auto STAGE, auto FIRST, bool with_transform) {
+  // pm: bit q set = position q of this wave's half is issued (polyphase form: positions whose U is zero by construction are not)
+  auto multiply = [&](auto STAGE, auto FIRST, bool with_transform, uint32_t pm) {
     constexpr int stage = decltype(STAGE)::value;
     constexpr bool first = decltype(FIRST)::value;
     using NEXT = std::integral_constant<int, 1 - stage>;
@@ -235,7 +272,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
     auto pair = [&](auto Q) {
       constexpr int q = decltype(Q)::value, set = (q >> 1) & 1;
       using std::integral_constant;
-      if constexpr (q + 2 < 8) rd(1 - set, q + 2);
+      if constexpr (q + 2 < 8) {
+        if (!POLY || first || (pm & (0xCu << q))) rd(1 - set, q + 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const float4 x0 = af[set][0], y0 = bf[set][0], x1 = af[set][1], y1 = bf[set][1];
 #ifdef WINO_EXP_NOMFMA
@@ -246,16 +285,27 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         const floatx16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, zero, 0, 0, 0);
         acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, zero, 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
+        acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
+        acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
+        acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
       } else {
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, acc[q], 0, 0, 0);
-        acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, acc[q + 1], 0, 0, 0);
+        // (wave-uniform tests; the four MFMAs of a position in a row: alternating two accumulators measured the same, experiments/r06.md 2)
+        if (!POLY || ((pm >> q) & 1u)) {
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
+        }
+        if (!POLY || ((pm >> (q + 1)) & 1u)) {
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, acc[q + 1], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
+        }
       }
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
-      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
-      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
-      acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #ifndef WINO_EXP_NOXFORM
@@ -307,7 +357,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       issue_raw_at(kb, c + 2);
       issue_u_at(kb, c + 1);
 #endif
-      multiply(STAGE, FIRST, c + 1 < nch || kb + 1u < n_mine);
+      uint32_t pm = 0xFFu;
+      if (poly) {  // phase 2 py + px of this chunk: j == 3 (q = 3, 7) is zero for px = 1, i == 3 (the upper half's q = 4 .. 7) for py = 1
+        const int ph2 = c >> cpp_shift;
+        pm = 0xFFu & ~((ph2 & 1) ? 0x88u : 0u) & ~(((ph2 >> 1) && ph) ? 0xF0u : 0u);
+      }
+      multiply(STAGE, FIRST, c + 1 < nch || kb + 1u < n_mine, pm);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
@@ -536,27 +591,65 @@ int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t 
   return check_launch("winograd_weights");
 }
 
+// Polyphase form of the 5x5 stride-2 kernel (include/aivc_hip.h): phase 2 py + px holds the taps ky = 2 r + py, kx = 2 l + px
+// as a 3x3 kernel g[r][l] (zero where ky or kx would be 5), U = G g G^T as above; virtual input channel phase * c_in + ci of a
+// 4 c_in-channel layer in the staging order of AIVC_WINO_U_INDEX.
+__global__ void __launch_bounds__(256) winograd_weights_poly5_kernel(const float *w, int c_out, int c_in, float *u) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)c_out * c_in * 4) return;
+  const int phase = (int)(idx % 4), ci = (int)((idx / 4) % c_in), co = (int)(idx / ((size_t)4 * c_in));
+  const int py = phase >> 1, px = phase & 1;
+  auto tap = [&](int r, int l) -> double {
+    const int ky = 2 * r + py, kx = 2 * l + px;
+    return ky < 5 && kx < 5 ? (double)w[(((size_t)co * 5 + ky) * 5 + kx) * c_in + ci] : 0.0;
+  };
+  double t[4][3], uu[4][4];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    double col[4];
+    wino_g(tap(0, l), tap(1, l), tap(2, l), col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][l] = col[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wino_g(t[i][0], t[i][1], t[i][2], uu[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[AIVC_WINO_U_INDEX(co, 4 * i + j, phase * c_in + ci, 4 * c_in)] = (float)uu[i][j];
+}
+
+int winograd_weights_poly5(const float *w, int c_out, int c_in, float *u, hipStream_t s) {
+  hipLaunchKernelGGL(winograd_weights_poly5_kernel, dim3(cdiv((size_t)c_out * c_in * 4, 256)), dim3(256), 0, s, w, c_out, c_in, u);
+  return check_launch("winograd_weights_poly5");
+}
+
 // what the kernel can address: 32-bit byte offsets inside one image
 bool conv2d_wino_supported(const aivc_conv_params &p) {
   if (!aivc_winograd_covers(&p) || p.gdn) return false;
   if ((uint64_t)p.h_in * p.w_in * p.c_in * 4u >= 0xFFFF0000ull) return false;
-  const uint64_t blocks = (uint64_t)p.n * (((uint64_t)p.h_in + 15) / 16) * (((uint64_t)p.w_in + 15) / 16) * ((uint64_t)p.c_out / 64);
+  const uint64_t blocks = (uint64_t)p.n * (((uint64_t)p.h_out + 15) / 16) * (((uint64_t)p.w_out + 15) / 16) * ((uint64_t)p.c_out / 64);
   return blocks < 0x7FFFFFFFull;
 }
 
-int conv2d_wino_variant(const aivc_conv_params &) { return 301; }
+int conv2d_wino_variant(const aivc_conv_params &p) { return p.ksize == 5 ? 302 : 301; }
 
 int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
   if (!conv2d_wino_supported(p) || !p.w_wino) return AIVC_ERR_UNSUPPORTED;
   WinoArgs a;
   a.p = p;
-  a.TH = (p.h_in + 1) / 2;
-  a.TW = (p.w_in + 1) / 2;
+  a.poly = p.ksize == 5 ? 1 : 0;
+  a.cpp_shift = 0;
+  while ((8 << a.cpp_shift) < p.c_in) ++a.cpp_shift;  // (polyphase form: c_in / 8 is a power of two, aivc_winograd_covers)
+  a.TH = (p.h_out + 1) / 2;
+  a.TW = (p.w_out + 1) / 2;
   a.nby = (a.TH + 7) / 8;
   a.nbx = (a.TW + 7) / 8;
   a.gy = p.c_out / 64;
-  static LdsOptIn opt_in;
-  if (!opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel), WINO_LDS)) return check_launch("conv_wino lds attribute");
+  static LdsOptIn opt_in, opt_in_poly;
+  if (!(a.poly ? opt_in_poly.raise(reinterpret_cast<const void *>(conv_wino_kernel<true>), WINO_LDS)
+               : opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel<false>), WINO_LDS)))
+    return check_launch("conv_wino lds attribute");
   a.total = (int)((size_t)p.n * a.nby * a.nbx * a.gy);
   static std::atomic<int> n_cu{0};
   if (n_cu.load(std::memory_order_relaxed) == 0) {
@@ -566,7 +659,8 @@ int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
   // persistent workgroups, one per CU (158 KB of LDS each); a multiple of 8 so that every XCD gets its share of the list
   unsigned grid = (unsigned)n_cu.load(std::memory_order_relaxed);
   if ((unsigned)a.total < grid) grid = (unsigned)a.total;
-  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WINO_LDS, s, a);
+  if (a.poly) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WINO_LDS, s, a);
+  else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WINO_LDS, s, a);
   return check_launch("conv_wino");
 }
 

@@ -164,9 +164,10 @@ def winograd_weights(w_ohwi):
     if hit is not None and hit[0]() is w_ohwi and hit[1] == stamp:
         return hit[2]
     co, k, _, ci = w_ohwi.shape
-    out = torch.empty(co * 16 * ci, dtype=torch.float32, device=w_ohwi.device)  # (the kernels' staging order, AIVC_WINO_U_INDEX)
+    n_virtual = 4 * ci if k == 5 else ci  # (5x5 stride 2: the polyphase form, aivc_winograd_weights_poly5)
+    out = torch.empty(co * 16 * n_virtual, dtype=torch.float32, device=w_ohwi.device)  # (the kernels' staging order, AIVC_WINO_U_INDEX)
     torch.cuda.synchronize(w_ohwi.device)
-    call('aivc_winograd_weights', _p(w_ohwi), co, ci, _p(out), _stream())
+    call('aivc_winograd_weights_poly5' if k == 5 else 'aivc_winograd_weights', _p(w_ohwi), co, ci, _p(out), _stream())
     torch.cuda.synchronize(w_ohwi.device)
     _WINO_WEIGHTS[key] = (weakref.ref(w_ohwi, lambda _r, k_=key: _WINO_WEIGHTS.pop(k_, None)), stamp, out)
     return out
@@ -174,8 +175,14 @@ def winograd_weights(w_ohwi):
 
 def _winograd_covers(mode, k, stride, pad, c, co, act1, act2, h, w, tail=False):
     """include/aivc_hip.h: aivc_winograd_covers"""
-    return mode == abi.MODE_CONV and k == 3 and stride == 1 and pad == 1 and c % 32 == 0 and co % 128 == 0 and not tail \
-        and act1 != 3 and act2 != 3 and (h * w >= abi.WINO_MIN_PIXELS or WINO_ANY_SIZE)
+    if mode != abi.MODE_CONV or co % 128 or tail or act1 == 3 or act2 == 3:
+        return False
+    if k == 3 and stride == 1 and pad == 1 and c % 32 == 0:
+        return h * w >= abi.WINO_MIN_PIXELS or WINO_ANY_SIZE
+    if k == 5 and stride == 2 and pad == 2 and c >= 32 and c & (c - 1) == 0:  # polyphase form: the size rule counts OUTPUT pixels
+        ho, wo = abi.conv_out_size(mode, h, w, k, stride, pad)
+        return ho * wo >= abi.WINO_MIN_PIXELS or WINO_ANY_SIZE
+    return False
 
 
 WINO_ANY_SIZE = False  # tests: fp32w on images below AIVC_WINO_MIN_PIXELS too (aivc_conv_params.flags, AIVC_CONV_WINO_ANY_SIZE)
@@ -256,6 +263,10 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     taps = k * k
     pix = n * h * w_ if mode == abi.MODE_TCONV else n * ho * wo
     flops = 2.0 * taps * c_real * co * pix + (2.0 * co * co * n * ho * wo if gdn is not None else 0.0)
+    if variant == 302:  # 5x5 stride 2 in polyphase form: 49 multiplications per 2 x 2 outputs and channel pair instead of 100
+        PROFILE_DIRECT_EQUIVALENT[0] += flops
+        flops = 2.0 * 49 * c_real * co * n * ((ho + 1) // 2) * ((wo + 1) // 2)
+        PROFILE_DIRECT_EQUIVALENT[1] += flops
     if variant == 301:
         # version 2 of the contract: what the matrix pipe EXECUTES (16 multiplications per tile of 2 x 2 outputs and channel
         # pair instead of 36) -- a roofline fraction is priced on issued work; the tap chain's count is kept beside it

@@ -59,6 +59,8 @@ def variant_name(v):
         return 'conv_mfma<conv,128x64+tail1x1>'
     if v == 301:
         return 'conv_wino<8x8 tiles,64>'
+    if v == 302:
+        return 'conv_wino<5x5s2 polyphase>'
     if v == 400:
         return 'gdn_resident'
     if v >= 1000:
@@ -715,7 +717,7 @@ def main():
                 el_v2 = time.time() - t0
             wino = [0, 0.0, 0.0]
             for variant, flops, e0, e1, _shape in ops.PROFILE:
-                if variant == 301:
+                if variant in (301, 302):
                     wino[0] += 1
                     wino[1] += flops
                     wino[2] += e0.elapsed_time(e1) * 1e-3

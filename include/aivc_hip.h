@@ -62,7 +62,7 @@ enum {
  * Library identity
  * ---------------------------------------------------------------------------------------- */
 /* ABI version, bumped whenever a struct or signature changes (the library and the CPU oracle both return it). */
-#define AIVC_ABI_VERSION 16
+#define AIVC_ABI_VERSION 17
 int aivc_abi_version(void);
 /* Last HIP runtime error string seen by this thread's most recent failing call (host). */
 const char *aivc_last_error(void);
@@ -156,10 +156,23 @@ typedef struct aivc_conv_params {
                                    * quantise the image badly and a launch is a handful of blocks per CU (34 x 60: no gain; the 68 x 120
                                    * layers of a 1080p frame are covered: x1.26 ... 1.42 on batches of 16 ... 64 frames) */
 #define AIVC_CONV_WINO_ANY_SIZE 2 /* aivc_conv_params.flags: version 2 whatever the image size (the tests drive the kernel on shapes the oracle checks in seconds) */
+/* ... and (ABI 17) for the 5x5 STRIDE-2 convolutions with replicate padding 2, c_in = 32 * 2^k, c_out % 128 == 0, no fused 1x1 tail and
+ * at least AIVC_WINO_MIN_PIXELS OUTPUT pixels (the second analysis layer of both networks, src/layers/misc/custom_conv_layers.py:129-180:
+ * a quarter of the codec's multiplications), in POLYPHASE form: output pixel (oy, ox) sums, over the four phases (py, px) of the input,
+ * a stride-1 3x3 convolution of the phase image  X_ph[y][x] = x[clamp(2 y + py)][clamp(2 x + px)]  (the replicate padding of the ORIGINAL
+ * image) with the phase kernel  g_ph[r][l] = w[2 r + py][2 l + px]  (zero where that index would be 5).  Exactly the chain above on a
+ * layer of 4 c_in "virtual" input channels  cv = (2 py + px) * c_in + ci  (phases ascending, channels of a phase in groups of 8 in
+ * AIVC_K_ORDER), with  d[r][c] = X_ph[2 ty - 1 + r][2 tx - 1 + c]  and  U_p[co][cv] = (G g_ph G^T)[i][j];  the positions whose U is zero
+ * by construction -- i == 3 for py = 1, j == 3 for px = 1 -- take no part in M_p: 16 + 12 + 12 + 9 = 49 multiplications per 2x2 outputs,
+ * input and output channel instead of 100.  U = aivc_winograd_weights_poly5(w). */
 static inline int aivc_winograd_covers(const aivc_conv_params *p) {
-  return p->mode == AIVC_MODE_CONV && p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0 &&
-         p->c_out % 128 == 0 && p->tail_c_out == 0 && p->act1 != AIVC_ACT_SIGMOID && p->act2 != AIVC_ACT_SIGMOID &&
-         ((int64_t)p->h_in * p->w_in >= AIVC_WINO_MIN_PIXELS || (p->flags & AIVC_CONV_WINO_ANY_SIZE));
+  if (p->mode != AIVC_MODE_CONV || p->c_out % 128 != 0 || p->tail_c_out != 0 || p->act1 == AIVC_ACT_SIGMOID || p->act2 == AIVC_ACT_SIGMOID)
+    return 0;
+  if (p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0)
+    return (int64_t)p->h_in * p->w_in >= AIVC_WINO_MIN_PIXELS || (p->flags & AIVC_CONV_WINO_ANY_SIZE);
+  if (p->ksize == 5 && p->stride == 2 && p->pad == 2 && p->c_in >= 32 && (p->c_in & (p->c_in - 1)) == 0)
+    return (int64_t)p->h_out * p->w_out >= AIVC_WINO_MIN_PIXELS || (p->flags & AIVC_CONV_WINO_ANY_SIZE);
+  return 0;
 }
 /* Epilogue order:  v = acc + bias;  [mode GDN: v = x / sqrtf(v) | mode IGDN: v = x * sqrtf(v)];
  *                  [fused gdn: with t_j = v_j * v_j over the pixel's channels,
@@ -181,6 +194,9 @@ int aivc_conv2d(const aivc_conv_params *p, aivc_stream_t stream);
   ((((((size_t)((co) / 64) * (size_t)((c_in) / 8) + (size_t)((ci) / 8)) * 16 + (size_t)(p)) * 2 + (size_t)(((ci) % 8) / 4)) * 64 + \
     (size_t)((co) % 64)) * 4 + (size_t)((ci) % 4))
 int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
+/* ABI 17: the polyphase form of a 5x5 stride-2 kernel (see aivc_winograd_covers): w is OHWI [c_out][5][5][c_in], u takes
+ * c_out * 16 * 4 * c_in floats -- the chunk images of a layer of 4 c_in virtual input channels, phase-major. */
+int aivc_winograd_weights_poly5(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
 
 /* AIVC_PREC_BF16X3, weights split ahead of the launches (aivc_conv_params.w_bf16x3): every weight of w [c_out][k_total]
  * (k_total = ksize * ksize * c_in, a multiple of 32: the OHWI rows of aivc_conv2d) as its three bf16 terms

@@ -109,7 +109,11 @@ def winograd_weights(w_ohwi):
     """[co, 3, 3, ci] -> co * 16 * ci floats in the staging order of include/aivc_hip.h (AIVC_WINO_U_INDEX)"""
     w_ohwi = _f32(w_ohwi)
     co, k, _, ci = w_ohwi.shape
-    assert k == 3
+    assert k in (3, 5)
+    if k == 5:  # polyphase form of the 5x5 stride-2 layers: 4 ci virtual channels
+        u = np.empty(co * 16 * 4 * ci, np.float32)
+        _chk(lib()['aivc_winograd_weights_poly5'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights_poly5')
+        return u
     u = np.empty(co * 16 * ci, np.float32)
     _chk(lib()['aivc_winograd_weights'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights')
     return u

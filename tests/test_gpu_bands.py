@@ -15,8 +15,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, scope='module')
-def _version_1_of_the_contract():
+@pytest.fixture(autouse=True)
+def _version_1_of_the_contract(_contract_does_not_leak):
     """Row bands are bit exact because every output of version 1 of the arithmetic contract is one chain over its own
     window whatever tensor the window is cut from; a Winograd chain of version 2 (the default) depends on the tile grid and
     size of the tensor it is computed in, and FrameCodec._banded never bands there."""

@@ -230,10 +230,13 @@ def test_split_weights_ahead_of_the_launch_change_no_bit(case, cuda):
         ops.PRESPLIT_WEIGHTS = True
         ops.set_precision(prev)
     assert torch.equal(out[False], out[True])
-    ops.set_precision('fp32')
-    taps = (k * k + 3) // 4 if mode == abi.MODE_TCONV else k * k
-    if taps * ci >= 512:  # (shorter reductions stay on the fp32 kernels)
-        assert not torch.equal(ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g, res=res), out[True])  # (the mode did run)
+    prev = ops.set_precision('fp32')
+    try:
+        taps = (k * k + 3) // 4 if mode == abi.MODE_TCONV else k * k
+        if taps * ci >= 512:  # (shorter reductions stay on the fp32 kernels)
+            assert not torch.equal(ops.conv2d(x, wt, b, mode=mode, stride=s, pad=pad, gdn=g, res=res), out[True])  # (the mode did run)
+    finally:
+        ops.set_precision(prev)
 
 
 def test_fused_tail_layer_in_the_mode(cuda):

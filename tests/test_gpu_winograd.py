@@ -187,8 +187,12 @@ def test_codec_in_version_2_equals_the_oracle_bytes_and_frames(cuda, oracle):
     synth.calibrate_operating_point(model, cuda)
     frames = synth.synthetic_video(512, 512, 3, seed=9)
     fc = model.frame_codec()
-    with torch.no_grad():
-        blob1 = fc.assemble_video(fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2'))
+    prev_h = ops.set_precision('fp32')
+    try:
+        with torch.no_grad():
+            blob1 = fc.assemble_video(fc.encode_video(synth.to_device_frames(frames, cuda), '1_GOP_2'))  # version 1's bytes
+    finally:
+        ops.set_precision(prev_h)
     prev_h, prev_o = ops.set_precision('fp32w'), oracle.set_precision('fp32w')
     ops.PROFILE = []
     try:
@@ -197,7 +201,7 @@ def test_codec_in_version_2_equals_the_oracle_bytes_and_frames(cuda, oracle):
             blob = fc.assemble_video(enc)
             dec, _, _, _ = fc.decode_video(blob, cuda)
         torch.cuda.synchronize()
-        n_wino = sum(1 for pr in ops.PROFILE if pr[0] == 301)
+        n_wino = sum(1 for pr in ops.PROFILE if pr[0] in (301, 302))
         ops.PROFILE = None
         assert fc.stream_errors() == []
         spec = ospec.export_model(model)
@@ -242,3 +246,105 @@ def test_wide_reference_fixtures_in_version_2(cuda, golden):
         print('  %-22s %.2e | %.2e' % (k, e0, e1))
     assert took >= 3, 'only %d of the wide fixtures took a Winograd launch' % took
     assert max(e[1] for e in worst.values()) <= 2e-5, worst
+
+
+# ---- the 5x5 stride-2 layers in polyphase form (ABI 17: four stride-1 3x3 convolutions of the input's phases, 49 multiplications per
+# 2x2 outputs instead of 100; include/aivc_hip.h, aivc_winograd_covers) -------------------------------------------------------------
+POLY_CASES = [  # n, h, w, c_in, c_out, act1, act2, bias, res
+    (1, 8, 8, 32, 128, 0, 0, True, False),
+    (2, 15, 17, 64, 128, 1, 0, True, False),     # odd input sizes: the last phase row / column clamps into the other phase's samples
+    (1, 33, 47, 64, 128, 0, 2, True, True),
+    (1, 64, 96, 64, 128, 0, 0, True, False),     # 32 x 48 outputs: 2 x 3 blocks
+    (3, 9, 7, 32, 256, 2, 0, False, False),      # four 64-channel blocks, tiny images
+    (1, 136, 240, 64, 128, 0, 0, True, True),    # 68 x 120 outputs: right-edge column, bottom block row mostly outside
+    (1, 7, 5, 128, 128, 0, 1, True, True),
+    (1, 1, 1, 32, 128, 0, 0, True, False),       # a single pixel: every tap clamps onto it
+    (2, 34, 62, 64, 128, 1, 0, True, True),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(POLY_CASES)))
+def test_polyphase_5x5_stride_2_hip_equals_oracle_bit_for_bit(idx, cuda, oracle, fp32w):
+    from aivc_amd import ops
+    n, h, w, ci, co, a1, a2, has_b, has_r = POLY_CASES[idx]
+    rng = np.random.default_rng(500 + idx)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
+    wt = (rng.standard_normal((co, 5, 5, ci)) / np.sqrt(25 * ci)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32) if has_b else None
+    ho, wo = abi.conv_out_size(abi.MODE_CONV, h, w, 5, 2, 2)
+    r = rng.standard_normal((n, ho, wo, co)).astype(np.float32) if has_r else None
+    want = oracle.conv2d(x, wt, b, stride=2, pad=2, act1=a1, act2=a2, res=r)
+    dv = lambda a: None if a is None else T(a, cuda)
+    ops.PROFILE = []
+    try:
+        got = ops.conv2d(dv(x), dv(wt), dv(b), stride=2, pad=2, act1=a1, act2=a2, res=dv(r))
+        torch.cuda.synchronize()
+        variants = [pr[0] for pr in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert variants == [302], variants
+    g = got.cpu().numpy()
+    assert np.array_equal(g, want), (POLY_CASES[idx], float(np.abs(g - want).max()))
+    # and within summation noise of version 1 (the tap chain) on the same inputs
+    prev = ops.set_precision('fp32')
+    try:
+        v1 = ops.conv2d(dv(x), dv(wt), dv(b), stride=2, pad=2, act1=a1, act2=a2, res=dv(r)).cpu().numpy()
+    finally:
+        ops.set_precision(prev)
+    assert np.abs(g - v1).max() <= 2e-5 * max(1.0, float(np.abs(v1).max()))
+
+
+def test_polyphase_weight_transform_equals_oracle(cuda, oracle):
+    from aivc_amd import ops
+    rng = np.random.default_rng(19)
+    w = (rng.standard_normal((64, 5, 5, 32)) * 3).astype(np.float32)
+    u = ops.winograd_weights(T(w, cuda)).cpu().numpy()
+    assert u.size == 64 * 16 * 4 * 32
+    assert np.array_equal(u, oracle.winograd_weights(w))
+    # positions that are zero by construction: i == 3 for py = 1, j == 3 for px = 1 (virtual channel = phase * c_in + ci)
+    img = u.reshape(1, 16, 16, 2, 64, 4)  # [co / 64][cv / 8][p][(cv % 8) / 4][co % 64][cv % 4]
+    for phase in range(4):
+        py, px = phase >> 1, phase & 1
+        chunks = img[:, 4 * phase:4 * phase + 4]
+        for pos in range(16):
+            i, j = pos >> 2, pos & 3
+            zero = (py == 1 and i == 3) or (px == 1 and j == 3)
+            assert (np.abs(chunks[:, :, pos]).max() == 0.0) == zero, (phase, pos)
+
+
+def test_polyphase_error_against_fp64_next_to_version_1(cuda):
+    from aivc_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 80, 104, 64)).astype(np.float32) * 3
+    wt = (rng.standard_normal((128, 5, 5, 64)) / np.sqrt(25 * 64)).astype(np.float32)
+    b = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (2, 2, 2, 2), mode='replicate'),
+                                     torch.from_numpy(wt).double().permute(0, 3, 1, 2), torch.from_numpy(b).double(), stride=2)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    errs = {}
+    for mode in ('fp32', 'fp32w'):
+        prev = ops.set_precision(mode)
+        ops.WINO_ANY_SIZE = True
+        try:
+            y = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=2, pad=2).cpu().numpy()
+        finally:
+            ops.WINO_ANY_SIZE = False
+            ops.set_precision(prev)
+        e = np.abs(y - ref) / np.maximum(1.0, np.abs(ref))
+        errs[mode] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
+    print('\n5x5 stride 2, max / rms error vs fp64: version 1 %.2e / %.2e, polyphase Winograd %.2e / %.2e' % (errs['fp32'] + errs['fp32w']))
+    assert errs['fp32w'][0] <= max(2e-5, 4 * errs['fp32'][0]) and errs['fp32w'][1] <= 3 * errs['fp32'][1]
+
+
+def test_polyphase_fused_gdn_request_is_two_launches_with_the_oracle_bits(cuda, oracle, fp32w):
+    from aivc_amd import ops
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((2, 21, 19, 64)).astype(np.float32)
+    wt = (rng.standard_normal((128, 5, 5, 64)) / np.sqrt(25 * 64)).astype(np.float32)
+    b = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    beta = (1.0 + rng.uniform(0, .5, 128)).astype(np.float32)
+    gamma = (0.1 * np.eye(128) + rng.uniform(0, .05, (128, 128))).astype(np.float32)
+    want = oracle.conv2d(x, wt, b, stride=2, pad=2, gdn=(beta, gamma, False))
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=2, pad=2, gdn=(T(beta, cuda), T(gamma, cuda), False))
+    assert np.array_equal(got.cpu().numpy(), want)
