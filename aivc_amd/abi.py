@@ -27,6 +27,7 @@ MAX_MAPS = 256
 RC_MAX_STREAMS = 64
 RATE_LANES = 16384
 WINO_MIN_PIXELS = 8000  # include/aivc_hip.h: AIVC_WINO_MIN_PIXELS
+WINO_MIN_PIXELS_TCONV = 32768  # ... AIVC_WINO_MIN_PIXELS_TCONV
 
 FRAME_I, FRAME_P, FRAME_B = 0, 1, 2
 
@@ -108,6 +109,7 @@ PROTOTYPES = {
     'aivc_split_weights_bf16x3': [_f, _i32, _i32, C.c_void_p],
     'aivc_winograd_weights': [_f, _i32, _i32, _f],
     'aivc_winograd_weights_poly5': [_f, _i32, _i32, _f],
+    'aivc_winograd_weights_tconv5': [_f, _i32, _i32, _f],
     'aivc_pad_channels': [_f, _sz, _i32, _f, _i32],
     'aivc_yuv420_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],
     'aivc_yuv420u8_to_444': [_f, _f, _f, _i32, _i32, _i32, _f, _i32, _i32, _i32],

@@ -100,6 +100,11 @@ AIVC_EXPORT int aivc_winograd_weights_poly5(const float *w, int32_t c_out, int32
   return aivc::winograd_weights_poly5(w, c_out, c_in, u, aivc::to_stream(stream));
 }
 
+AIVC_EXPORT int aivc_winograd_weights_tconv5(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream) {
+  if (!w || !u || c_out <= 0 || c_in <= 0 || c_out % 64 || c_in % 8) return AIVC_ERR_ARG;
+  return aivc::winograd_weights_tconv5(w, c_out, c_in, u, aivc::to_stream(stream));
+}
+
 AIVC_EXPORT int aivc_conv_images(const aivc_image_src *src, int32_t n_img, const aivc_conv_params *p, aivc_stream_t stream) {
   if (!p || !p->w || !p->y || !src || n_img < 1 || n_img > AIVC_MAX_IMAGES) return AIVC_ERR_ARG;
   if (p->n <= 0 || p->h_in <= 0 || p->w_in <= 0) return AIVC_ERR_ARG;

@@ -133,9 +133,10 @@ int split_weights_bf16x3(const float *w, int c_out, int k_total, void *out, hipS
 int conv2d_bf16x3_tile(const aivc_conv_params &p);  // tile id of the mode's launch (aivc_conv2d_variant)  // 100 + 10*mode + tile id (+50 fused gdn); 190 fused 1x1 tail
 bool conv2d_wino_supported(const aivc_conv_params &p);  // conv_wino.hip: AIVC_PREC_FP32_WINO, what the kernel can address (no fused gdn)
 int conv2d_wino(const aivc_conv_params &p, hipStream_t s);
-int conv2d_wino_variant(const aivc_conv_params &p);  // 301: 3x3 stride 1, 302: 5x5 stride 2 in polyphase form
+int conv2d_wino_variant(const aivc_conv_params &p);  // 301: 3x3 stride 1, 302: 5x5 stride 2 in polyphase form, 303: transposed 5x5 stride 2 by classes
 int winograd_weights(const float *w, int c_out, int c_in, float *u, hipStream_t s);
 int winograd_weights_poly5(const float *w, int c_out, int c_in, float *u, hipStream_t s);  // 5x5 stride 2 in polyphase form
+int winograd_weights_tconv5(const float *w, int c_out, int c_in, float *u, hipStream_t s);  // transposed 5x5 stride 2, class by class
 bool gdn_resident_supported(const aivc_conv_params &p);  // gdn.hip: stand-alone (I)GDN of 64 / 128 channels, gamma resident in registers
 int gdn_resident(const aivc_conv_params &p, hipStream_t s);  // variant 400
 bool conv_images_supported(const aivc_image_src *src, int n_img, const aivc_conv_params &p);

@@ -55,9 +55,17 @@ constexpr int WINO_V_POS = 2 * WINO_V_QUAD;
 constexpr int WINO_V_STAGE = 16 * WINO_V_POS;
 constexpr int WINO_LDS = 2 * (WINO_RAW_STAGE + WINO_U_STAGE + WINO_V_STAGE);
 
-// POLY: the polyphase form of the 5x5 stride-2 layers (a separate instantiation: the stride-1 3x3 kernel pays nothing for it)
-template <bool POLY>
+// 4 KB of zeros: the source of the patch pixels outside the image in the transposed form (zero extension; an LDS-DMA cannot fill)
+__device__ __attribute__((aligned(4096))) float wino_zeros[1024];
+
+// MODE 0: stride-1 3x3.  MODE 1 (POLY): the polyphase form of the 5x5 stride-2 convolutions.  MODE 2 (TC): the 5x5 stride-2
+// TRANSPOSED convolutions: each of the four output parity classes is a stride-1 3x3 correlation of the (zero-extended) input with
+// the class's taps padded with zeros -- a block of the list is (pixel block, class, 64 output channels), the outputs of class
+// (pyc, pxc) land on pixels (2 y + pyc, 2 x + pxc); positions with i == 0 (pyc = 1) or j == 0 (pxc = 1) have U = 0 and are not issued.
+// Separate instantiations: the stride-1 3x3 kernel pays nothing for the others.
+template <int MODE>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
+  constexpr bool POLY = MODE == 1, TC = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char wsmem[];
   char *raw = wsmem, *Us = wsmem + 2 * WINO_RAW_STAGE, *Vs = Us + 2 * WINO_U_STAGE;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)wsmem;
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   // c >> cpp_shift = 2 py + px, whose patch pixel (y, x) is input pixel (clamp(2 y + py), clamp(2 x + px)) -- the replicate
   // padding of the ORIGINAL image -- and whose 3x3 kernel is the phase's taps padded with zeros: positions with i == 3 (py = 1)
   // or j == 3 (px = 1) have U = 0 and are not issued (49 instead of 64 of the 4 x 16 position products).
-  const int H = p.h_out, W = p.w_out, Hi = p.h_in, Wi = p.w_in, Cin = p.c_in, Cout = p.c_out;
+  const int H = TC ? p.h_in : p.h_out, W = TC ? p.w_in : p.w_out, Hi = p.h_in, Wi = p.w_in, Cin = p.c_in, Cout = p.c_out;
+  const int gyc = TC ? 4 * a.gy : a.gy;  // entries of the block list per pixel block: channel blocks (x 4 classes)
   constexpr int poly = POLY ? 1 : 0;
   const int cpp_shift = a.cpp_shift, cpp_mask = (1 << a.cpp_shift) - 1;
 
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   struct Desc {
     const float *xbase, *ubase;
     uint32_t r_off[2];  // stride-1 form: per-lane byte offsets of the block's raw patch (the polyphase form keeps those of the phase being issued)
-    int img, byi, bxi, cb;
+    int img, byi, bxi, cb;  // cb: channel block (transposed form: class * gy + channel block)
   };
   // raw: instruction k of 11 writes slots 64 k .. 64 k + 63; wave w issues k = w and, for w < 3, k = w + 8.  slot = (plane *
   // 81 + hy * 9 + hx) * 2 + quad with plane = (py & 1) * 2 + (px & 1), hy = py >> 1, hx = px >> 1 for patch pixel (py, px)
@@ -107,15 +116,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   const int nch = poly ? 4 * (Cin >> 3) : (Cin >> 3);  // chunks of 8 (virtual) input channels per block
   auto make_desc = [&](uint32_t blk) {
     Desc d;
-    d.cb = (int)(blk % (uint32_t)a.gy);
-    uint32_t rest = blk / (uint32_t)a.gy;
+    d.cb = (int)(blk % (uint32_t)gyc);
+    uint32_t rest = blk / (uint32_t)gyc;
     d.bxi = (int)(rest % (uint32_t)a.nbx);
     rest /= (uint32_t)a.nbx;
     d.byi = (int)(rest % (uint32_t)a.nby);
     d.img = (int)(rest / (uint32_t)a.nby);
     d.xbase = p.x + (size_t)d.img * (size_t)Hi * Wi * Cin;                       // this image (32-bit byte offsets inside it)
     d.ubase = p.w_wino + (size_t)d.cb * (size_t)nch * (WINO_U_STAGE / 4);        // this channel block's chunk images
-    if constexpr (!POLY) {
+    if constexpr (MODE == 0) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int iy = max(min(16 * d.byi - 1 + s_py[k], Hi - 1), 0), ix = max(min(16 * d.bxi - 1 + s_px[k], Wi - 1), 0);
@@ -135,6 +144,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       iss_off[k] = ((uint32_t)(iy * Wi + ix) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
     }
   };
+  // transposed form: per-lane 64-bit source addresses of the chunk being issued (a pixel outside the image reads zeros), advanced
+  // by the 32 bytes of a chunk after every issue, recomputed when the issue stream enters a block
+  uint64_t iss_addr[2];
+  auto tc_addresses = [&](const Desc &d_) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int iy = 16 * d_.byi - 1 + s_py[k], ix = 16 * d_.bxi - 1 + s_px[k];
+      const bool in = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+      const uint64_t a_in = (uint64_t)(uintptr_t)d_.xbase + ((uint64_t)((uint32_t)(iy * Wi + ix)) * (uint32_t)Cin + (uint32_t)(4 * s_quad[k])) * 4u;
+      const uint64_t a_z = (uint64_t)(uintptr_t)wino_zeros + (uint32_t)(16 * s_quad[k]);
+      iss_addr[k] = in ? a_in : a_z;
+    }
+  };
   Desc cur = make_desc(block_of(0)), nxt = n_mine > 1u ? make_desc(block_of(1)) : cur;
 
   const uint32_t r_dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
@@ -147,7 +169,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   };
   auto issue_raw = [&](const Desc &d_, int c) {  // chunk c of block d_ -> raw stage c & 1 (chunks are issued in order)
     const uint32_t d = r_dst + (uint32_t)((c & 1) * WINO_RAW_STAGE);
-    if constexpr (POLY) {
+    if constexpr (TC) {
+      if (c == 0) tc_addresses(d_);
+      const uint32_t du = __builtin_amdgcn_readfirstlane(d);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(iss_addr[0]), "s"(du) : "memory", "m0");
+      if (wave < 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(iss_addr[1]), "s"(du + 8192u) : "memory", "m0");
+      iss_addr[0] += 32u;
+      iss_addr[1] += 32u;
+    } else if constexpr (POLY) {
       if ((c & cpp_mask) == 0) patch_offsets(d_, c >> cpp_shift);  // the issue stream enters a phase
       const float *src = uniform_ptr(d_.xbase + 8 * (c & cpp_mask));
       const uint32_t du = __builtin_amdgcn_readfirstlane(d);  // (under register pressure the compiler parks the uniform in a VGPR)
@@ -159,17 +188,43 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       if (wave < 3) wino_glds16(src, d_.r_off[1], d + 8192u);
     }
   };
+  // zero-by-construction positions (polyphase / transposed forms): is position (i, j) of phase / class `pc` zero?
+  auto zero_pos = [&](int pc, int i, int j) -> bool {
+    if constexpr (POLY) return ((pc >> 1) && i == 3) || ((pc & 1) && j == 3);
+    if constexpr (TC) return ((pc >> 1) && i == 0) || ((pc & 1) && j == 0);
+    return false;
+  };
+  auto phase_or_class = [&](const Desc &d_, int c) -> int { return POLY ? c >> cpp_shift : (TC ? d_.cb / a.gy : 0); };
   auto issue_u = [&](const Desc &d_, int c) {  // chunk c of block d_ -> U stage c & 1: a straight copy of the chunk image
-    const float *src = POLY ? uniform_ptr(d_.ubase + (size_t)c * (WINO_U_STAGE / 4)) : d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
-    const uint32_t d = POLY ? __builtin_amdgcn_readfirstlane(u_dst + (uint32_t)((c & 1) * WINO_U_STAGE)) : u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
+    const float *src = MODE != 0 ? uniform_ptr(d_.ubase + (size_t)c * (WINO_U_STAGE / 4)) : d_.ubase + (size_t)c * (WINO_U_STAGE / 4);
+    const uint32_t d = MODE != 0 ? __builtin_amdgcn_readfirstlane(u_dst + (uint32_t)((c & 1) * WINO_U_STAGE)) : u_dst + (uint32_t)((c & 1) * WINO_U_STAGE);
     // four instructions off ONE M0: the instruction offset advances the global and the LDS address alike (the chunk image is
-    // contiguous on both sides)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %1\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:3072"
-                 : : "v"(u_off), "s"(src), "s"(d) : "memory", "m0");
+    // contiguous on both sides).  This wave's four pieces are positions 2 wave (two channel quads) and 2 wave + 1: a position whose
+    // U is zero by construction is neither multiplied nor fetched
+    bool lo = true, hi = true;
+    if constexpr (MODE != 0) {
+      const int pc = phase_or_class(d_, c), i = wave >> 1, j = 2 * (wave & 1);
+      lo = !zero_pos(pc, i, j);
+      hi = !zero_pos(pc, i, j + 1);
+    }
+    if (lo && hi) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:3072"
+                   : : "v"(u_off), "s"(src), "s"(d) : "memory", "m0");
+    } else if (lo) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024"
+                   : : "v"(u_off), "s"(src), "s"(d) : "memory", "m0");
+    } else if (hi) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:3072"
+                   : : "v"(u_off), "s"(src), "s"(d) : "memory", "m0");
+    }
   };
 
   // ---- transform plan: thread = (tile, channel quad, row i of the 4 x 4 positions) -----------------------------------------
@@ -253,7 +308,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
   // other's gaps without any phase arrangement
   // FIRST: the block's first chunk starts its accumulators from the inline constant 0 (no clearing pass after the fold)
   // pm: bit q set = position q of this wave's half is issued (polyphase form: positions whose U is zero by construction are not)
-  auto multiply = [&](auto STAGE, auto FIRST, bool with_transform, uint32_t pm) {
+  // tm: bit s set = step s of the NEXT chunk's transform is run (0: no transform rides along)
+  auto multiply = [&](auto STAGE, auto FIRST, uint32_t tm, uint32_t pm) {
     constexpr int stage = decltype(STAGE)::value;
     constexpr bool first = decltype(FIRST)::value;
     using NEXT = std::integral_constant<int, 1 - stage>;
@@ -273,7 +329,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       constexpr int q = decltype(Q)::value, set = (q >> 1) & 1;
       using std::integral_constant;
       if constexpr (q + 2 < 8) {
-        if (!POLY || first || (pm & (0xCu << q))) rd(1 - set, q + 2);
+        if (MODE == 0 || (first && !TC) || (pm & (0xCu << q))) rd(1 - set, q + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
       const float4 x0 = af[set][0], y0 = bf[set][0], x1 = af[set][1], y1 = bf[set][1];
@@ -281,7 +337,27 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       acc[q][0] += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
       acc[q + 1][0] += x1.x * y1.x + x1.y * y1.y + x1.z * y1.z + x1.w * y1.w;
 #else
-      if constexpr (first) {
+      if constexpr (first && TC) {
+        // the block's first chunk: a position the class does not issue gets a cleared accumulator (one MFMA of zeros), the others
+        // start from the inline zero
+        const floatx16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if ((pm >> q) & 1u) {
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, zero, 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
+        } else {
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.0f, 0.0f, zero, 0, 0, 0);
+        }
+        if ((pm >> (q + 1)) & 1u) {
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, zero, 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
+        } else {
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.0f, 0.0f, zero, 0, 0, 0);
+        }
+      } else if constexpr (first) {
         const floatx16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, zero, 0, 0, 0);
         acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, zero, 0, 0, 0);
@@ -293,13 +369,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, y1.w, acc[q + 1], 0, 0, 0);
       } else {
         // (wave-uniform tests; the four MFMAs of a position in a row: alternating two accumulators measured the same, experiments/r06.md 2)
-        if (!POLY || ((pm >> q) & 1u)) {
+        if (MODE == 0 || ((pm >> q) & 1u)) {
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, y0.z, acc[q], 0, 0, 0);
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, y0.w, acc[q], 0, 0, 0);
         }
-        if (!POLY || ((pm >> (q + 1)) & 1u)) {
+        if (MODE == 0 || ((pm >> (q + 1)) & 1u)) {
           acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, acc[q + 1], 0, 0, 0);
           acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, acc[q + 1], 0, 0, 0);
           acc[q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, y1.z, acc[q + 1], 0, 0, 0);
@@ -309,10 +385,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #ifndef WINO_EXP_NOXFORM
-      if (with_transform) {
-        transform_step(NEXT{}, integral_constant<int, q>{});
-        transform_step(NEXT{}, integral_constant<int, q + 1>{});
-      }
+      if ((tm >> q) & 1u) transform_step(NEXT{}, integral_constant<int, q>{});
+      if ((tm >> (q + 1)) & 1u) transform_step(NEXT{}, integral_constant<int, q + 1>{});
 #endif
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -362,7 +436,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         const int ph2 = c >> cpp_shift;
         pm = 0xFFu & ~((ph2 & 1) ? 0x88u : 0u) & ~(((ph2 >> 1) && ph) ? 0xF0u : 0u);
       }
-      multiply(STAGE, FIRST, c + 1 < nch || kb + 1u < n_mine, pm);
+      if constexpr (TC) {  // class 2 pyc + pxc of this block: i == 0 (the lower half's q = 0 .. 3) is zero for pyc = 1, j == 0 (q = 0, 4) for pxc = 1
+        // (the block's FIRST chunk issues every position: those multiply by U = 0 and clear their accumulators)
+        const int cls = cur.cb / a.gy;
+        pm = 0xFFu & ~((cls & 1) ? 0x11u : 0u) & ~(((cls >> 1) && !ph) ? 0x0Fu : 0u);
+      }
+      // the transform of chunk c + 1 (the next block's chunk 0 behind this block's last): this thread computes the positions
+      // (i = t_i, j = 0 .. 3) -- nothing if row i is zero by construction in that chunk's phase / class, not V_j if column j is
+      uint32_t tm = (c + 1 < nch || kb + 1u < n_mine) ? 0xFFu : 0u;
+      if constexpr (MODE != 0) {
+        const int pcn = c + 1 < nch ? phase_or_class(cur, c + 1) : phase_or_class(nxt, 0);
+        if (zero_pos(pcn, t_i, 1)) tm = 0u;  // (j = 1 is never zero by construction: the row is)
+        else if (zero_pos(pcn, 1, POLY ? 3 : 0)) tm &= POLY ? ~0x80u : ~0x10u;
+      }
+      multiply(STAGE, FIRST, tm, pm);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
@@ -439,7 +526,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
       const float *__restrict__ g_mul = p.mul;
       const float *__restrict__ g_res = p.res;
       float *__restrict__ g_y = p.y;
-      const int co = cur.cb * 64 + 32 * wn + l31;
+      // transposed form: this block's class (pyc, pxc); output pixel of grid pixel (y, x) = (2 y + pyc, 2 x + pxc) of a 2 H x 2 W image
+      const int cls = TC ? cur.cb / a.gy : 0, pyc = cls >> 1, pxc = cls & 1;
+      const int OS = TC ? 2 : 1;                     // output pixels per grid pixel and axis
+      const int Wo_ = OS * W, Ho_ = OS * H;
+      const int co = (TC ? cur.cb - cls * a.gy : cur.cb) * 64 + 32 * wn + l31;
       const bool has_bias = p.bias != nullptr;
       const float cbias = has_bias ? p.bias[co] : 0.0f;
       const int oy_w = 2 * (8 * cur.byi + 4 * wm) + ph;  // output row of the wave's first tile row (wave-uniform)
@@ -453,10 +544,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         typedef __attribute__((address_space(1))) char gchar;
         typedef __attribute__((address_space(1))) float gfloat;
         typedef __attribute__((address_space(1))) const float cgfloat;
-        const uint32_t c4 = (uint32_t)Cout * 4u;
-        uint32_t lane_b = (uint32_t)(2 * (8 * cur.bxi + 4 * hh)) * c4 + (uint32_t)co * 4u;
+        const uint32_t c4 = (uint32_t)Cout * 4u, sx = (uint32_t)OS * c4;  // bytes per output pixel / per grid pixel along x
+        uint32_t lane_b = (uint32_t)(2 * (8 * cur.bxi + 4 * hh)) * sx + (uint32_t)pxc * c4 + (uint32_t)co * 4u;
         asm volatile("" : "+v"(lane_b));
-        const size_t img_b = (size_t)cur.img * (size_t)H * W * c4;
+        const size_t img_b = (size_t)cur.img * (size_t)Ho_ * Wo_ * c4;
         auto rows = [&](auto RES, auto KIND, auto EDGE) {
           constexpr bool has_res = decltype(RES)::value;
           constexpr bool edge = decltype(EDGE)::value;
@@ -470,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
           for (int rq = 0; rq < 4; ++rq) {
             const int oy = oy_w + 2 * rq;
             if (oy >= H) continue;  // wave-uniform
-            const size_t row_b = img_b + (size_t)oy * W * c4;
+            const size_t row_b = img_b + (size_t)(OS * oy + pyc) * Wo_ * c4;
             gchar *yb = (gchar *)(uintptr_t)(reinterpret_cast<char *>(g_y) + row_b);
             const gchar *rb = (const gchar *)(uintptr_t)(reinterpret_cast<const char *>(g_res) + row_b);
             float rv[8];
@@ -479,7 +570,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
               for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                  rv[rr * 2 + b] = ok[rr * 2 + b] ? *reinterpret_cast<cgfloat *>(rb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) : 0.0f;
+                  rv[rr * 2 + b] = ok[rr * 2 + b] ? *reinterpret_cast<cgfloat *>(rb + lane_b + (uint32_t)((2 * rr + b) * 512) * (sx / 512u)) : 0.0f;
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
@@ -496,7 +587,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
 #ifdef WINO_EXP_NOSTORE
                 if (v == 123.456f)
 #endif
-                if (ok[rr * 2 + b]) *reinterpret_cast<gfloat *>(yb + lane_b + (uint32_t)((2 * rr + b) * 512) * (c4 / 512u)) = v;
+                if (ok[rr * 2 + b]) *reinterpret_cast<gfloat *>(yb + lane_b + (uint32_t)((2 * rr + b) * 512) * (sx / 512u)) = v;
               }
           }
         };
@@ -506,7 +597,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         if (act1 == AIVC_ACT_NONE && act2 == AIVC_ACT_NONE) kind = 0;
         else if (act2 == AIVC_ACT_NONE) kind = act1 == AIVC_ACT_LEAKY ? 1 : 2;
         else if (act1 == AIVC_ACT_NONE) kind = act2 == AIVC_ACT_RELU ? 3 : 4;
-        if (kind >= 0 && Cout % 128 == 0) {
+        if (kind >= 0 && sx % 512u == 0u) {
           auto go = [&](auto RES, auto EDGE) {
             switch (kind) {
               case 0: rows(RES, integral_constant<int, 0>{}, EDGE); break;
@@ -527,7 +618,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
         }
       }
       {
-        const size_t ybase = (size_t)cur.img * (size_t)H * W * Cout + (size_t)co;
+        const size_t ybase = (size_t)cur.img * (size_t)Ho_ * Wo_ * Cout + (size_t)co;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;  // tile of the wave's 4 x 8
@@ -537,7 +628,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoArgs a) {
           for (int b = 0; b < 2; ++b) {
             const int ox = ox0 + b;
             if (ox >= W) continue;
-            const size_t o = ybase + ((size_t)oy * W + ox) * (size_t)Cout;
+            const size_t o = ybase + ((size_t)(OS * oy + pyc) * Wo_ + (size_t)(OS * ox + pxc)) * (size_t)Cout;
             float v = keep[b][r];
             if (has_bias) v = v + cbias;
             v = act_cheap(act1, v);
@@ -624,33 +715,73 @@ int winograd_weights_poly5(const float *w, int c_out, int c_in, float *u, hipStr
   return check_launch("winograd_weights_poly5");
 }
 
+// Transposed 5x5 stride-2 kernel, class by class (include/aivc_hip.h): class 2 pyc + pxc holds the taps ky = pyc + 4 - 2 r,
+// kx = pxc + 4 - 2 l as a 3x3 kernel g[r][l] (zero where ky or kx would be 5: r = 0 for pyc = 1), U = G g G^T; output channel
+// block class * (c_out / 64) + co / 64 of a layer of 4 c_out "virtual" output channels in the staging order of AIVC_WINO_U_INDEX.
+__global__ void __launch_bounds__(256) winograd_weights_tconv5_kernel(const float *w, int c_out, int c_in, float *u) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)c_out * c_in * 4) return;
+  const int ci = (int)(idx % c_in), co = (int)((idx / c_in) % c_out), cls = (int)(idx / ((size_t)c_in * c_out));
+  const int pyc = cls >> 1, pxc = cls & 1;
+  auto tap = [&](int r, int l) -> double {
+    const int ky = pyc + 4 - 2 * r, kx = pxc + 4 - 2 * l;
+    return ky < 5 && kx < 5 ? (double)w[(((size_t)co * 5 + ky) * 5 + kx) * c_in + ci] : 0.0;
+  };
+  double t[4][3], uu[4][4];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    double col[4];
+    wino_g(tap(0, l), tap(1, l), tap(2, l), col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][l] = col[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wino_g(t[i][0], t[i][1], t[i][2], uu[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[AIVC_WINO_U_INDEX(cls * c_out + co, 4 * i + j, ci, c_in)] = (float)uu[i][j];
+}
+
+int winograd_weights_tconv5(const float *w, int c_out, int c_in, float *u, hipStream_t s) {
+  hipLaunchKernelGGL(winograd_weights_tconv5_kernel, dim3(cdiv((size_t)c_out * c_in * 4, 256)), dim3(256), 0, s, w, c_out, c_in, u);
+  return check_launch("winograd_weights_tconv5");
+}
+
 // what the kernel can address: 32-bit byte offsets inside one image
 bool conv2d_wino_supported(const aivc_conv_params &p) {
   if (!aivc_winograd_covers(&p) || p.gdn) return false;
   if ((uint64_t)p.h_in * p.w_in * p.c_in * 4u >= 0xFFFF0000ull) return false;
-  const uint64_t blocks = (uint64_t)p.n * (((uint64_t)p.h_out + 15) / 16) * (((uint64_t)p.w_out + 15) / 16) * ((uint64_t)p.c_out / 64);
+  const bool tc = p.mode == AIVC_MODE_TCONV;
+  const uint64_t gh = tc ? p.h_in : p.h_out, gw = tc ? p.w_in : p.w_out;  // the pixel grid the blocks walk
+  const uint64_t blocks = (uint64_t)p.n * ((gh + 15) / 16) * ((gw + 15) / 16) * ((uint64_t)p.c_out / 64) * (tc ? 4 : 1);
   return blocks < 0x7FFFFFFFull;
 }
 
-int conv2d_wino_variant(const aivc_conv_params &p) { return p.ksize == 5 ? 302 : 301; }
+int conv2d_wino_variant(const aivc_conv_params &p) { return p.mode == AIVC_MODE_TCONV ? 303 : (p.ksize == 5 ? 302 : 301); }
+
+template <int MODE>
+static int wino_launch(const WinoArgs &a, unsigned grid, hipStream_t s) {
+  static LdsOptIn opt_in;
+  if (!opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel<MODE>), WINO_LDS)) return check_launch("conv_wino lds attribute");
+  hipLaunchKernelGGL(conv_wino_kernel<MODE>, dim3(grid), dim3(512), WINO_LDS, s, a);
+  return check_launch("conv_wino");
+}
 
 int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
   if (!conv2d_wino_supported(p) || !p.w_wino) return AIVC_ERR_UNSUPPORTED;
+  const bool tc = p.mode == AIVC_MODE_TCONV;
   WinoArgs a;
   a.p = p;
-  a.poly = p.ksize == 5 ? 1 : 0;
+  a.poly = !tc && p.ksize == 5 ? 1 : 0;
   a.cpp_shift = 0;
   while ((8 << a.cpp_shift) < p.c_in) ++a.cpp_shift;  // (polyphase form: c_in / 8 is a power of two, aivc_winograd_covers)
-  a.TH = (p.h_out + 1) / 2;
-  a.TW = (p.w_out + 1) / 2;
+  a.TH = ((tc ? p.h_in : p.h_out) + 1) / 2;
+  a.TW = ((tc ? p.w_in : p.w_out) + 1) / 2;
   a.nby = (a.TH + 7) / 8;
   a.nbx = (a.TW + 7) / 8;
   a.gy = p.c_out / 64;
-  static LdsOptIn opt_in, opt_in_poly;
-  if (!(a.poly ? opt_in_poly.raise(reinterpret_cast<const void *>(conv_wino_kernel<true>), WINO_LDS)
-               : opt_in.raise(reinterpret_cast<const void *>(conv_wino_kernel<false>), WINO_LDS)))
-    return check_launch("conv_wino lds attribute");
-  a.total = (int)((size_t)p.n * a.nby * a.nbx * a.gy);
+  a.total = (int)((size_t)p.n * a.nby * a.nbx * a.gy * (tc ? 4 : 1));
   static std::atomic<int> n_cu{0};
   if (n_cu.load(std::memory_order_relaxed) == 0) {
     int dev = 0, cus = 0;
@@ -659,9 +790,8 @@ int conv2d_wino(const aivc_conv_params &p, hipStream_t s) {
   // persistent workgroups, one per CU (158 KB of LDS each); a multiple of 8 so that every XCD gets its share of the list
   unsigned grid = (unsigned)n_cu.load(std::memory_order_relaxed);
   if ((unsigned)a.total < grid) grid = (unsigned)a.total;
-  if (a.poly) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WINO_LDS, s, a);
-  else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WINO_LDS, s, a);
-  return check_launch("conv_wino");
+  if (tc) return wino_launch<2>(a, grid, s);
+  return a.poly ? wino_launch<1>(a, grid, s) : wino_launch<0>(a, grid, s);
 }
 
 }  // namespace aivc

@@ -154,20 +154,21 @@ def split_weights_bf16x3(w_ohwi):
 _WINO_WEIGHTS = {}  # id(weight tensor) -> (weak reference, (data_ptr, version), U)
 
 
-def winograd_weights(w_ohwi):
-    """aivc_winograd_weights of an OHWI 3x3 weight ([co, 3, 3, ci] -> co * 16 * ci floats), once per tensor and version
-    (aivc_conv_params.w_wino); closed with a device-wide wait like every other kernel-ready parameter."""
+def winograd_weights(w_ohwi, transposed=False):
+    """aivc_winograd_weights of an OHWI 3x3 weight ([co, 3, 3, ci] -> co * 16 * ci floats), aivc_winograd_weights_poly5 of a 5x5
+    stride-2 one (4 ci virtual input channels) or, transposed, aivc_winograd_weights_tconv5 (4 co virtual output channels), once per
+    tensor and version (aivc_conv_params.w_wino); closed with a device-wide wait like every other kernel-ready parameter."""
     import weakref
-    key = id(w_ohwi)
+    key = (id(w_ohwi), bool(transposed))
     stamp = (w_ohwi.data_ptr(), w_ohwi._version)
     hit = _WINO_WEIGHTS.get(key)
     if hit is not None and hit[0]() is w_ohwi and hit[1] == stamp:
         return hit[2]
     co, k, _, ci = w_ohwi.shape
-    n_virtual = 4 * ci if k == 5 else ci  # (5x5 stride 2: the polyphase form, aivc_winograd_weights_poly5)
-    out = torch.empty(co * 16 * n_virtual, dtype=torch.float32, device=w_ohwi.device)  # (the kernels' staging order, AIVC_WINO_U_INDEX)
+    fn = 'aivc_winograd_weights_tconv5' if transposed else ('aivc_winograd_weights_poly5' if k == 5 else 'aivc_winograd_weights')
+    out = torch.empty(co * 16 * ci * (4 if k == 5 else 1), dtype=torch.float32, device=w_ohwi.device)  # (the kernels' staging order, AIVC_WINO_U_INDEX)
     torch.cuda.synchronize(w_ohwi.device)
-    call('aivc_winograd_weights_poly5' if k == 5 else 'aivc_winograd_weights', _p(w_ohwi), co, ci, _p(out), _stream())
+    call(fn, _p(w_ohwi), co, ci, _p(out), _stream())
     torch.cuda.synchronize(w_ohwi.device)
     _WINO_WEIGHTS[key] = (weakref.ref(w_ohwi, lambda _r, k_=key: _WINO_WEIGHTS.pop(k_, None)), stamp, out)
     return out
@@ -175,7 +176,11 @@ def winograd_weights(w_ohwi):
 
 def _winograd_covers(mode, k, stride, pad, c, co, act1, act2, h, w, tail=False):
     """include/aivc_hip.h: aivc_winograd_covers"""
-    if mode != abi.MODE_CONV or co % 128 or tail or act1 == 3 or act2 == 3:
+    if tail or act1 == 3 or act2 == 3:
+        return False
+    if mode == abi.MODE_TCONV:  # transposed 5x5 stride 2, class by class: the size rule counts INPUT pixels
+        return k == 5 and stride == 2 and c % 32 == 0 and co % 64 == 0 and (h * w >= abi.WINO_MIN_PIXELS_TCONV or WINO_ANY_SIZE)
+    if mode != abi.MODE_CONV or co % 128:
         return False
     if k == 3 and stride == 1 and pad == 1 and c % 32 == 0:
         return h * w >= abi.WINO_MIN_PIXELS or WINO_ANY_SIZE
@@ -253,7 +258,7 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
         if load()['aivc_conv2d_variant'](C.byref(p)) >= 1000:  # a launch the mode covers
             p.w_bf16x3 = _p(split_weights_bf16x3(w_ohwi))
     if PRECISION == abi.PREC_FP32_WINO and _winograd_covers(mode, k, stride, pad, c, co, act1, act2, h, w_):
-        p.w_wino = _p(winograd_weights(w_ohwi if w_ohwi.is_contiguous() else w_ohwi.contiguous()))
+        p.w_wino = _p(winograd_weights(w_ohwi if w_ohwi.is_contiguous() else w_ohwi.contiguous(), transposed=mode == abi.MODE_TCONV))
     if PROFILE is None:
         call('aivc_conv2d', C.byref(p), _stream())
         return y
@@ -263,6 +268,10 @@ def conv2d(x, w_ohwi, bias=None, mode=abi.MODE_CONV, stride=1, pad=0, act1=0, ac
     taps = k * k
     pix = n * h * w_ if mode == abi.MODE_TCONV else n * ho * wo
     flops = 2.0 * taps * c_real * co * pix + (2.0 * co * co * n * ho * wo if gdn is not None else 0.0)
+    if variant == 303:  # transposed 5x5 stride 2 by classes: 49 multiplications per 2 x 2 grid pixels (4 x 4 outputs) and channel pair instead of 100
+        PROFILE_DIRECT_EQUIVALENT[0] += flops
+        flops = 2.0 * 49 * c_real * co * n * ((h + 1) // 2) * ((w_ + 1) // 2)
+        PROFILE_DIRECT_EQUIVALENT[1] += flops
     if variant == 302:  # 5x5 stride 2 in polyphase form: 49 multiplications per 2 x 2 outputs and channel pair instead of 100
         PROFILE_DIRECT_EQUIVALENT[0] += flops
         flops = 2.0 * 49 * c_real * co * n * ((ho + 1) // 2) * ((wo + 1) // 2)

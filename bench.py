@@ -61,6 +61,8 @@ def variant_name(v):
         return 'conv_wino<8x8 tiles,64>'
     if v == 302:
         return 'conv_wino<5x5s2 polyphase>'
+    if v == 303:
+        return 'conv_wino<tconv5x5s2 classes>'
     if v == 400:
         return 'gdn_resident'
     if v >= 1000:
@@ -717,7 +719,7 @@ def main():
                 el_v2 = time.time() - t0
             wino = [0, 0.0, 0.0]
             for variant, flops, e0, e1, _shape in ops.PROFILE:
-                if variant in (301, 302):
+                if variant in (301, 302, 303):
                     wino[0] += 1
                     wino[1] += flops
                     wino[2] += e0.elapsed_time(e1) * 1e-3

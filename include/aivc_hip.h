@@ -155,6 +155,8 @@ typedef struct aivc_conv_params {
 #define AIVC_WINO_MIN_PIXELS 8000 /* h_in * w_in from which the version applies: below it the 16 x 16-pixel blocks of the kernel
                                    * quantise the image badly and a launch is a handful of blocks per CU (34 x 60: no gain; the 68 x 120
                                    * layers of a 1080p frame are covered: x1.26 ... 1.42 on batches of 16 ... 64 frames) */
+#define AIVC_WINO_MIN_PIXELS_TCONV 32768 /* ... of the transposed form (INPUT pixels): a class pass is 16 chunks of 6 positions per wave on
+                                         * average, so a block's fixed costs weigh more (68 x 120: x0.93, 272 x 480: x1.2) */
 #define AIVC_CONV_WINO_ANY_SIZE 2 /* aivc_conv_params.flags: version 2 whatever the image size (the tests drive the kernel on shapes the oracle checks in seconds) */
 /* ... and (ABI 17) for the 5x5 STRIDE-2 convolutions with replicate padding 2, c_in = 32 * 2^k, c_out % 128 == 0, no fused 1x1 tail and
  * at least AIVC_WINO_MIN_PIXELS OUTPUT pixels (the second analysis layer of both networks, src/layers/misc/custom_conv_layers.py:129-180:
@@ -165,9 +167,19 @@ typedef struct aivc_conv_params {
  * AIVC_K_ORDER), with  d[r][c] = X_ph[2 ty - 1 + r][2 tx - 1 + c]  and  U_p[co][cv] = (G g_ph G^T)[i][j];  the positions whose U is zero
  * by construction -- i == 3 for py = 1, j == 3 for px = 1 -- take no part in M_p: 16 + 12 + 12 + 9 = 49 multiplications per 2x2 outputs,
  * input and output channel instead of 100.  U = aivc_winograd_weights_poly5(w). */
+/* ... and for the 5x5 stride-2 TRANSPOSED convolutions with c_in % 32 == 0, c_out % 64 == 0 and at least AIVC_WINO_MIN_PIXELS_TCONV INPUT
+ * pixels (the synthesis layers, src/layers/misc/custom_conv_layers.py:183-253), class by class: the outputs of parity class (pyc, pxc),
+ * y[2 v + pyc][2 u + pxc], are a stride-1 3x3 correlation of the ZERO-extended input with the class kernel
+ * g_c[r][l] = w[pyc + 4 - 2 r][pxc + 4 - 2 l]  (zero where that index would be 5, i.e. r = 0 for pyc = 1, l = 0 for pxc = 1): the chain
+ * above with  d[r][c] = x[2 tv - 1 + r][2 tu - 1 + c]  (0 outside the image)  for the tile of grid pixels (2 tv + a, 2 tu + b),
+ * U_p[co][ci] = (G g_c G^T)[i][j],  and the positions whose U is zero by construction -- i == 0 for pyc = 1, j == 0 for pxc = 1 -- taking
+ * no part in M_p (49 instead of 100 multiplications per 4x4 outputs ...).  U = aivc_winograd_weights_tconv5(w). */
 static inline int aivc_winograd_covers(const aivc_conv_params *p) {
-  if (p->mode != AIVC_MODE_CONV || p->c_out % 128 != 0 || p->tail_c_out != 0 || p->act1 == AIVC_ACT_SIGMOID || p->act2 == AIVC_ACT_SIGMOID)
-    return 0;
+  if (p->tail_c_out != 0 || p->act1 == AIVC_ACT_SIGMOID || p->act2 == AIVC_ACT_SIGMOID) return 0;
+  if (p->mode == AIVC_MODE_TCONV)
+    return p->ksize == 5 && p->stride == 2 && p->c_in % 32 == 0 && p->c_out % 64 == 0 &&
+           ((int64_t)p->h_in * p->w_in >= AIVC_WINO_MIN_PIXELS_TCONV || (p->flags & AIVC_CONV_WINO_ANY_SIZE));
+  if (p->mode != AIVC_MODE_CONV || p->c_out % 128 != 0) return 0;
   if (p->ksize == 3 && p->stride == 1 && p->pad == 1 && p->c_in % 32 == 0)
     return (int64_t)p->h_in * p->w_in >= AIVC_WINO_MIN_PIXELS || (p->flags & AIVC_CONV_WINO_ANY_SIZE);
   if (p->ksize == 5 && p->stride == 2 && p->pad == 2 && p->c_in >= 32 && (p->c_in & (p->c_in - 1)) == 0)
@@ -197,6 +209,9 @@ int aivc_winograd_weights(const float *w, int32_t c_out, int32_t c_in, float *u,
 /* ABI 17: the polyphase form of a 5x5 stride-2 kernel (see aivc_winograd_covers): w is OHWI [c_out][5][5][c_in], u takes
  * c_out * 16 * 4 * c_in floats -- the chunk images of a layer of 4 c_in virtual input channels, phase-major. */
 int aivc_winograd_weights_poly5(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
+/* ABI 17: the class kernels of a transposed 5x5 stride-2 layer (see aivc_winograd_covers): w is OHWI [c_out][5][5][c_in]
+ * (w[co][ky][kx][ci] = torch weight[ci][co][ky][kx]), u takes 4 * c_out * 16 * c_in floats -- class-major blocks of 64 output channels. */
+int aivc_winograd_weights_tconv5(const float *w, int32_t c_out, int32_t c_in, float *u, aivc_stream_t stream);
 
 /* AIVC_PREC_BF16X3, weights split ahead of the launches (aivc_conv_params.w_bf16x3): every weight of w [c_out][k_total]
  * (k_total = ksize * ksize * c_in, a multiple of 32: the OHWI rows of aivc_conv2d) as its three bf16 terms

@@ -105,17 +105,15 @@ def set_precision(mode):
     return prev
 
 
-def winograd_weights(w_ohwi):
-    """[co, 3, 3, ci] -> co * 16 * ci floats in the staging order of include/aivc_hip.h (AIVC_WINO_U_INDEX)"""
+def winograd_weights(w_ohwi, transposed=False):
+    """[co, 3, 3, ci] -> co * 16 * ci floats in the staging order of include/aivc_hip.h (AIVC_WINO_U_INDEX); 5x5: the polyphase form
+    of a stride-2 kernel (4 ci virtual input channels) or, transposed, its class kernels (4 co virtual output channels)"""
     w_ohwi = _f32(w_ohwi)
     co, k, _, ci = w_ohwi.shape
-    assert k in (3, 5)
-    if k == 5:  # polyphase form of the 5x5 stride-2 layers: 4 ci virtual channels
-        u = np.empty(co * 16 * 4 * ci, np.float32)
-        _chk(lib()['aivc_winograd_weights_poly5'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights_poly5')
-        return u
-    u = np.empty(co * 16 * ci, np.float32)
-    _chk(lib()['aivc_winograd_weights'](_p(w_ohwi), co, ci, _p(u), None), 'aivc_winograd_weights')
+    assert k in (3, 5) and (k == 5 or not transposed)
+    u = np.empty(co * 16 * ci * (4 if k == 5 else 1), np.float32)
+    name = 'aivc_winograd_weights_tconv5' if transposed else ('aivc_winograd_weights_poly5' if k == 5 else 'aivc_winograd_weights')
+    _chk(lib()[name](_p(w_ohwi), co, ci, _p(u), None), name)
     return u
 
 

@@ -348,3 +348,75 @@ def test_polyphase_fused_gdn_request_is_two_launches_with_the_oracle_bits(cuda, 
     want = oracle.conv2d(x, wt, b, stride=2, pad=2, gdn=(beta, gamma, False))
     got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), stride=2, pad=2, gdn=(T(beta, cuda), T(gamma, cuda), False))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ---- the transposed 5x5 stride-2 layers class by class (ABI 17: each output parity class a stride-1 3x3 correlation of the
+# zero-extended input, 49 multiplications per 2x2 grid pixels instead of 100) ---------------------------------------------------------
+TC_CASES = [  # n, h, w, c_in, c_out, act1, act2, bias, res
+    (1, 8, 8, 32, 64, 0, 0, True, False),
+    (2, 7, 9, 64, 64, 1, 0, True, False),        # odd sizes: half-filled last tile row / column, zero extension on every side
+    (1, 17, 30, 128, 64, 0, 0, True, True),
+    (1, 33, 50, 128, 128, 0, 2, True, True),     # c_out 128: two channel blocks per class; interior + edge blocks
+    (3, 5, 3, 32, 128, 0, 0, False, False),      # tiny images: a block spans nothing but border
+    (1, 68, 120, 128, 64, 0, 0, True, False),    # the 1/16-resolution shape of 1080p: right-edge column
+    (1, 1, 1, 32, 64, 0, 0, True, False),
+    (2, 34, 60, 64, 128, 2, 0, True, True),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(TC_CASES)))
+def test_transposed_5x5_stride_2_hip_equals_oracle_bit_for_bit(idx, cuda, oracle, fp32w):
+    from aivc_amd import ops
+    n, h, w, ci, co, a1, a2, has_b, has_r = TC_CASES[idx]
+    rng = np.random.default_rng(700 + idx)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
+    wt = (rng.standard_normal((co, 5, 5, ci)) / np.sqrt(6.25 * ci)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32) if has_b else None
+    r = rng.standard_normal((n, 2 * h, 2 * w, co)).astype(np.float32) if has_r else None
+    want = oracle.conv2d(x, wt, b, mode=abi.MODE_TCONV, stride=2, act1=a1, act2=a2, res=r)
+    dv = lambda a: None if a is None else T(a, cuda)
+    ops.PROFILE = []
+    try:
+        got = ops.conv2d(dv(x), dv(wt), dv(b), mode=abi.MODE_TCONV, stride=2, act1=a1, act2=a2, res=dv(r))
+        torch.cuda.synchronize()
+        variants = [pr[0] for pr in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert variants == [303], variants
+    g = got.cpu().numpy()
+    assert np.array_equal(g, want), (TC_CASES[idx], float(np.abs(g - want).max()))
+    prev = ops.set_precision('fp32')  # within summation noise of version 1 (the tap chains of the classes)
+    try:
+        v1 = ops.conv2d(dv(x), dv(wt), dv(b), mode=abi.MODE_TCONV, stride=2, act1=a1, act2=a2, res=dv(r)).cpu().numpy()
+    finally:
+        ops.set_precision(prev)
+    assert np.abs(g - v1).max() <= 2e-5 * max(1.0, float(np.abs(v1).max()))
+
+
+def test_transposed_weight_transform_equals_oracle(cuda, oracle):
+    from aivc_amd import ops
+    rng = np.random.default_rng(29)
+    w = (rng.standard_normal((64, 5, 5, 32)) * 3).astype(np.float32)
+    u = ops.winograd_weights(T(w, cuda), transposed=True).cpu().numpy()
+    assert u.size == 4 * 64 * 16 * 32
+    assert np.array_equal(u, oracle.winograd_weights(w, transposed=True))
+    img = u.reshape(4, 4, 16, 2, 64, 4)  # [class (co_virtual / 64)][ci / 8][p][(ci % 8) / 4][co % 64][ci % 4]
+    for cls in range(4):
+        pyc, pxc = cls >> 1, cls & 1
+        for pos in range(16):
+            i, j = pos >> 2, pos & 3
+            zero = (pyc == 1 and i == 0) or (pxc == 1 and j == 0)
+            assert (np.abs(img[cls, :, pos]).max() == 0.0) == zero, (cls, pos)
+
+
+def test_transposed_fused_igdn_request_is_two_launches_with_the_oracle_bits(cuda, oracle, fp32w):
+    from aivc_amd import ops
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 11, 13, 128)).astype(np.float32)
+    wt = (rng.standard_normal((64, 5, 5, 128)) / np.sqrt(6.25 * 128)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    beta = (1.0 + rng.uniform(0, .5, 64)).astype(np.float32)
+    gamma = (0.1 * np.eye(64) + rng.uniform(0, .05, (64, 64))).astype(np.float32)
+    want = oracle.conv2d(x, wt, b, mode=abi.MODE_TCONV, stride=2, gdn=(beta, gamma, True))
+    got = ops.conv2d(T(x, cuda), T(wt, cuda), T(b, cuda), mode=abi.MODE_TCONV, stride=2, gdn=(T(beta, cuda), T(gamma, cuda), True))
+    assert np.array_equal(got.cpu().numpy(), want)
