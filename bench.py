@@ -525,14 +525,24 @@ def main():
             all_sec = sum(d[2] for d in mf.values())
             traffic, traffic_note, counters = None, None, None
             # counter passes on this shape (tools/pmc_conv.sh; separate --pmc runs, never inside this process): the newest round's
-            pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_pmc_dominant.json')))
-            pmc = pmcs[-1] if pmcs else ''
-            if pmc:
-                pj = json.load(open(pmc))
-                if pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)):
-                    traffic = pj.get('traffic_bytes_per_launch')
-                    traffic_note = 'counter passes at batch %s (the bench launches this kernel at 32 -- its 64-frame level in two halves -- 16, 8 and 4 frames); ' % pj.get('probe_batch') + pj.get('note')
-                    counters = pj.get('sq_counters')
+            # (the newest summary under profiles/ whose `kernel` is this run's dominant kernel: r0*_pmc_dominant.json of the tap
+            # kernels, tools/pmc_summary.py's r0*_pmc_<tag>.json of the Winograd / GDN kernels)
+            cands = []
+            for pmc in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_pmc_*.json'))):
+                try:
+                    pj = json.load(open(pmc))
+                except ValueError:
+                    continue
+                if isinstance(pj, dict) and pj.get('kernel') == VARIANT_NAMES.get(dom, str(dom)) and pj.get('traffic_bytes_per_launch'):
+                    cands.append((os.path.basename(pmc)[:3], pj.get('algorithmic_bytes_per_launch') or 0, pmc, pj))
+            if cands:
+                _, _, pmc, pj = max(cands, key=lambda c: (c[0], c[1]))  # the newest round's, its largest probe
+                traffic = pj.get('traffic_bytes_per_launch')
+                traffic_note = ('separate rocprofv3 --pmc passes on ONE launch shape of this kernel (%s): %d B per launch (FETCH_SIZE doubled per the guide) '
+                                'against %s B algorithmic (%sx), L2 hit rate %s; %s' % (
+                                    pj.get('probe', '?'), traffic, pj.get('algorithmic_bytes_per_launch'), pj.get('traffic_over_algorithmic'),
+                                    pj.get('l2_hit_rate'), pj.get('note', os.path.basename(pmc))))
+                counters = pj.get('sq_counters')
             roofline = {'bound': 'mfma', 'kernel': VARIANT_NAMES.get(dom, str(dom)),
                         'achieved': round(fl / sec / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_note': traffic_note,
