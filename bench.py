@@ -549,6 +549,13 @@ def main():
                         'mfma_counters': counters,
                         'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 2),
                         'gflop_per_launch': round(fl / cnt / 1e9, 3),
+                        # a Winograd instantiation is priced on the FLOPs it EXECUTES (what the matrix pipe is busy with); beside it the
+                        # rate on the tap-chain work of the same layers (36 / 16 of it for the 3x3 form, 100 / 49 for the 5x5 forms):
+                        # what the direct algorithm would have had to sustain for the same launch times -- above the peak by construction
+                        'flops_priced': 'executed' if dom in (301, 302, 303) else 'algorithmic',
+                        'tap_chain_equivalent': ({'achieved': round(fl / sec / 1e12 * (2.25 if dom == 301 else 100.0 / 49.0), 2),
+                                                  'frac': round(fl / sec / 1e12 * (2.25 if dom == 301 else 100.0 / 49.0) / MFMA_F32_PEAK_TFLOPS, 4)}
+                                                 if dom in (301, 302, 303) else None),
                         'all_mfma_conv': {'achieved': round(all_fl / all_sec / 1e12, 2),
                                           'frac': round(all_fl / all_sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                           'tflop_per_step': round(all_fl / 1e12, 3),
