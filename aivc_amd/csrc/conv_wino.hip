@@ -753,6 +753,7 @@ bool conv2d_wino_supported(const aivc_conv_params &p) {
   if (!aivc_winograd_covers(&p) || p.gdn) return false;
   if ((uint64_t)p.h_in * p.w_in * p.c_in * 4u >= 0xFFFF0000ull) return false;
   const bool tc = p.mode == AIVC_MODE_TCONV;
+  if (tc && p.c_in > 960) return false;  // (a pixel outside the image reads c_in floats of the 4 KB zero page, one chunk after the other)
   const uint64_t gh = tc ? p.h_in : p.h_out, gw = tc ? p.w_in : p.w_out;  // the pixel grid the blocks walk
   const uint64_t blocks = (uint64_t)p.n * ((gh + 15) / 16) * ((gw + 15) / 16) * ((uint64_t)p.c_out / 64) * (tc ? 4 : 1);
   return blocks < 0x7FFFFFFFull;
