@@ -75,3 +75,13 @@ def test_bench_weak_scaling_flag(cuda):
     assert out['scaling'] == 'weak' and out['n_gpus'] == 2 and out['closed_loop_ok'] is True
     assert abs(out['value'] - 2 * 64 / (out['ms_per_step'] * 1e-3)) < 0.02 * out['value']
     assert 'weak_scaling' not in out
+
+
+def test_bench_two_ranks_at_a_size_version_2_covers(cuda):
+    """1280x720: the 3x3 layers at 1/4 resolution (320 x 180) and both 5x5 forms run their Winograd kernels here (416x240 above is
+    below the contract's size rules) -- the sharded bitstream must still be the single rank's: a Winograd chain depends on the image,
+    never on the batch it is launched in"""
+    out, err = _run(2, ['--width', '1280', '--height', '720', '--frames', '18', '--gop', '1_GOP_8'])
+    assert out['n_gpus'] == 2 and out['arithmetic_contract'] == 'fp32w'
+    assert out['bytes_equal_single_rank'] is True and out['closed_loop_ok'] is True
+    assert out['stream_errors_rank0'] == 0
