@@ -64,7 +64,7 @@ def test_bench_one_unit_over_four_ranks_level_sharding_and_bands(cuda):
 
 def test_bench_one_unit_over_four_ranks_in_the_default_contract(cuda):
     """the same in the default (version 2) contract: level sharding only, row bands reported off, bytes still those of one rank"""
-    out, err = _run(4, ['--frames', '16', '--gop', '1_GOP_16'])
+    out, err = _run(4, ['--frames', '16', '--gop', '1_GOP_16', '--contract', 'fp32w'])
     assert out['n_gpus'] == 4 and out['scaling'] == 'strong' and out['arithmetic_contract'] == 'fp32w'
     assert out['bytes_equal_single_rank'] is True and out['closed_loop_ok'] is True
     assert out['row_bands'] is not None and out['row_bands'].startswith('off')
@@ -81,7 +81,7 @@ def test_bench_two_ranks_at_a_size_version_2_covers(cuda):
     """1280x720: the 3x3 layers at 1/4 resolution (320 x 180) and both 5x5 forms run their Winograd kernels here (416x240 above is
     below the contract's size rules) -- the sharded bitstream must still be the single rank's: a Winograd chain depends on the image,
     never on the batch it is launched in"""
-    out, err = _run(2, ['--width', '1280', '--height', '720', '--frames', '18', '--gop', '1_GOP_8'])
+    out, err = _run(2, ['--width', '1280', '--height', '720', '--frames', '18', '--gop', '1_GOP_8', '--contract', 'fp32w'])
     assert out['n_gpus'] == 2 and out['arithmetic_contract'] == 'fp32w'
     assert out['bytes_equal_single_rank'] is True and out['closed_loop_ok'] is True
     assert out['stream_errors_rank0'] == 0
